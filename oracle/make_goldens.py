@@ -1,0 +1,166 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's src/models on CPU.
+
+Development-container script (needs /root/reference; never runs on the GPU box).
+Only inputs' seeds and the reference's outputs are written - no reference source.
+The reference modules are imported unmodified; two runtime shims make them
+runnable without a GPU: Tensor.cuda becomes the identity, and while the
+reference Decoder runs, torch.randn returns the fixture's noise tensor so the
+draw at generator.py:248 is reproducible on any platform.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = os.environ.get('VCA_REFERENCE', '/root/reference')
+
+from oracle import cpu_ref, fixtures  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def import_reference():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    from src.models import generator as rg
+    from src.models import visual_front as rv
+    return rg, rv
+
+
+@contextlib.contextmanager
+def fixed_randn(noise):
+    orig = torch.randn
+
+    def fake(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        assert shape == tuple(noise.shape), (shape, noise.shape)
+        return noise.clone()
+    torch.randn = fake
+    try:
+        yield
+    finally:
+        torch.randn = orig
+
+
+class RefGen(torch.nn.Module):
+    """Adapter giving the reference Decoder the oracle's noise= keyword."""
+
+    def __init__(self, gen):
+        super().__init__()
+        self.inner = gen
+
+    def forward(self, s, x, lens, noise=None):
+        with fixed_randn(noise):
+            return self.inner(s, x, lens)
+
+
+def build_reference(rg, rv, seed):
+    m = dict(v_front=rv.Visual_front(in_channels=1), gen=rg.Decoder(), post=rg.Postnet(),
+             dis1=rg.Discriminator(phase='1'), dis2=rg.Discriminator(phase='2'),
+             dis3=rg.Discriminator(phase='3'), s_dis=rg.sync_Discriminator(temp=1.0))
+    return fixtures.fill_models(m, seed)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def forward_case(rg, rv, name, train, B=2, T=20, H=112, lens=(20, 13), seed=11):
+    torch.manual_seed(0)
+    m = build_reference(rg, rv, 100)
+    for k in m:
+        m[k].train(train)
+    b = fixtures.make_batch(B, T, H, seed, list(lens))
+    out = {}
+    with torch.no_grad():
+        phon, sent = m['v_front'](b['vid'])
+        with fixed_randn(b['noise']):
+            g1, g2, g3 = m['gen'](sent, phon, b['vid_len'])
+        gs = m['post'](g3)
+        mel = b['mel']
+        mel1 = torch.nn.functional.interpolate(mel, scale_factor=0.25, mode='bilinear')
+        mel2 = torch.nn.functional.interpolate(mel, scale_factor=0.5, mode='bilinear')
+        for i, (d, r, g) in enumerate(zip(('dis1', 'dis2', 'dis3'), (mel1, mel2, mel), (g1, g2, g3)), 1):
+            u, c = m[d](r, sent, T)
+            out['real_u%d' % i], out['real_c%d' % i] = np32(u), np32(c)
+            u, c = m[d](g, sent, T)
+            out['fake_u%d' % i], out['fake_c%d' % i] = np32(u), np32(c)
+        out['sync_d'] = np32(m['s_dis'](phon, mel))
+        out['sync_g'] = np32(m['s_dis'](phon, g3, True))
+    out.update(phon=np32(phon), sent=np32(sent), g1=np32(g1), g2=np32(g2), g3=np32(g3), gs=np32(gs))
+    if train:   # running statistics after one train-mode forward (a few representative BN layers)
+        for mod, key in (('v_front', 'frontend.1.running_mean'), ('v_front', 'frontend.1.running_var'),
+                         ('v_front', 'resnet.layer4.1.bn2.running_var'), ('gen', 'decode.0.norm1.running_mean'),
+                         ('gen', 'g3.2.norm2.running_var'), ('post', 'postnet.1.running_var'),
+                         ('s_dis', 'frontend.4.running_mean')):
+            out['stat:%s:%s' % (mod, key)] = np32(m[mod].state_dict()[key])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), B=B, T=T, H=H, lens=np.array(lens), seed=seed,
+                        wseed=100, **out)
+    print(name, {k: v.shape for k, v in out.items() if not k.startswith('stat')})
+
+
+def vfront_case(rg, rv, name, H, B=1, T=6, seed=21):
+    m = build_reference(rg, rv, 100)
+    vf = m['v_front'].eval()
+    b = fixtures.make_batch(B, T, H, seed)
+    with torch.no_grad():
+        phon, sent = vf(b['vid'])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), B=B, T=T, H=H, seed=seed, wseed=100,
+                        phon=np32(phon), sent=np32(sent))
+    print(name, phon.shape, sent.shape)
+
+
+def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, seed=31):
+    m = build_reference(rg, rv, 200)
+    for k in m:
+        m[k].train()
+    amsgrad = variant == 'grid'
+    opts = cpu_ref.build_optimizers(m, amsgrad=amsgrad)
+    drive = dict(m)
+    drive['gen'] = RefGen(m['gen'])          # same parameters; adapter only injects the noise
+    out = {}
+    for s in range(nsteps):
+        b = fixtures.make_batch(B, T, H, seed + s, list(lens))
+        res = cpu_ref.gan_step(drive, opts, b, variant=variant, noise=b['noise'])
+        for k in ('dis_loss', 'gen_loss', 'sync_loss', 'g_sync_loss', 'recon_loss', 'g_loss'):
+            out['s%d:%s' % (s, k)] = np.float64(res[k])
+        out['s%d:grad_p' % s] = np.array(res['grad_p'], dtype=np.float64)
+        for k in ('g1', 'g2', 'g3'):
+            out['s%d:%s' % (s, k)] = np32(res[k])
+        for mod in sorted(m):
+            gn, pn = 0.0, 0.0
+            for pname, p in m[mod].named_parameters():
+                idx = fixtures.sample_idx(p.numel(), 8, mod + '.' + pname)
+                out['s%d:param:%s:%s' % (s, mod, pname)] = np32(p).reshape(-1)[idx]
+                if p.grad is not None:
+                    out['s%d:grad:%s:%s' % (s, mod, pname)] = np32(p.grad).reshape(-1)[idx]
+                    gn += float(p.grad.double().pow(2).sum())
+                pn += float(p.detach().double().pow(2).sum())
+            out['s%d:gradnorm:%s' % (s, mod)] = np.float64(gn ** 0.5)
+            out['s%d:paramnorm:%s' % (s, mod)] = np.float64(pn ** 0.5)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), B=B, T=T, H=H, lens=np.array(lens), seed=seed,
+                        wseed=200, nsteps=nsteps, variant=variant, **out)
+    print(name, {k: float(v) for k, v in out.items() if k.endswith('_loss')})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    rg, rv = import_reference()
+    forward_case(rg, rv, 'fwd_eval', train=False)
+    forward_case(rg, rv, 'fwd_train', train=True)
+    vfront_case(rg, rv, 'vfront_h104', 104)
+    vfront_case(rg, rv, 'vfront_h128', 128)
+    step_case(rg, rv, 'step_grid', 'grid')
+    step_case(rg, rv, 'step_lrs', 'lrs')
+
+
+if __name__ == '__main__':
+    main()
