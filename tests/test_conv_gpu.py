@@ -1,0 +1,112 @@
+"""HIP implicit-GEMM convolution (through the C ABI) vs torch's CPU convolution: forward, input gradient, weight
+gradient, bias gradient and the grad-of-grad the R1 penalty needs.  fp32 tolerance: 2e-5 relative to the tensor's
+max magnitude (the MFMA accumulates in a different order than the CPU kernels)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return (a.detach().cpu().double() - b.detach().double()).abs().max().item() / (b.detach().abs().max().item() + 1e-12)
+
+
+CASES = [
+    # N, H, W, Cin, Cout, K, stride, pad, ups
+    (2, 9, 11, 32, 48, 5, 1, 2, 0),
+    (3, 12, 12, 64, 128, 3, 2, 1, 0),      # ResNet stride-2 block conv
+    (3, 12, 12, 64, 128, 1, 2, 0, 0),      # 1x1 stride-2 shortcut
+    (2, 5, 18, 48, 24, 5, 1, 0, 0),        # valid 5x5 head conv
+    (2, 10, 7, 16, 32, 5, 1, 2, 1),        # conv over a nearest x2 upsample
+    (2, 20, 13, 1, 32, 5, 1, 2, 0),        # single-channel input (discriminator stem)
+    (2, 20, 14, 1, 128, 3, 2, 1, 0),       # sync discriminator stem
+    (2, 8, 9, 32, 1, 1, 1, 0, 0),          # to_mel 1x1 to one channel
+    (1, 6, 5, 80, 321, 1, 1, 0, 0),        # odd Cout
+    (1, 7, 6, 321, 16, 1, 1, 0, 0),        # odd Cin
+    (2, 6, 6, 256, 256, 3, 1, 1, 0),
+]
+
+
+@gpu
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_fwd_bwd(case):
+    from vcagan_amd import ops
+    N, H, W, Cin, Cout, K, s, p, ups = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode='nearest') if ups else xr
+    yr = F.conv2d(xin, wr, br, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xd, wd, bd, s, p, ups)
+    assert y.shape == (N,) + tuple(yr.shape[2:]) + (Cout,)
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 2e-5
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 2e-5
+    assert rel_err(wd.grad, wr.grad) < 2e-5
+    assert rel_err(bd.grad, br.grad) < 2e-5
+
+
+@gpu
+@pytest.mark.parametrize('case', [(2, 12, 10, 1, 32, 5, 1, 2), (2, 6, 9, 32, 64, 5, 1, 2), (2, 5, 8, 64, 64, 5, 1, 0)])
+def test_conv2d_double_backward(case):
+    """d/dw of ||d y.sum / d x||^2 (the R1 penalty structure, train.py:188-194)."""
+    from vcagan_amd import ops
+    N, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w1 = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    w2 = torch.randn(Cout, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5
+
+    def penalty(conv, act, xx, a, b, nchw):
+        h = act(conv(xx, a, None, s, p))
+        out = conv(h, b, None, 1, 1)
+        gr, = torch.autograd.grad(out.sum(), xx, create_graph=True)
+        return (gr ** 2).sum()
+
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    a, b = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    pr = penalty(F.conv2d, lambda t: F.leaky_relu(t, 0.2), xr, a, b, True)
+    pr.backward()
+
+    xd = x.cuda().requires_grad_(True)
+    ad, bd = w1.cuda().requires_grad_(True), w2.cuda().requires_grad_(True)
+    pd = penalty(lambda t, ww, bb, ss, pp: ops.conv2d(t, ww, bb, ss, pp), lambda t: F.leaky_relu(t, 0.2), xd, ad, bd, False)
+    pd.backward()
+    assert abs(pd.item() - pr.item()) < 1e-4 * abs(pr.item())
+    assert rel_err(ad.grad, a.grad) < 1e-4
+    assert rel_err(bd.grad, b.grad) < 1e-4
+
+
+@gpu
+def test_conv1d_linear_stem():
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    # conv1d (Postnet, generator.py:178)
+    x = torch.randn(2, 37, 80, generator=g); w = torch.randn(128, 80, 7, generator=g) * 0.05; b = torch.randn(128, generator=g)
+    y = ops.conv1d(x.cuda(), w.cuda(), b.cuda(), 3)
+    assert rel_err(y, F.conv1d(x.transpose(1, 2), w, b, 1, 3).transpose(1, 2)) < 2e-5
+    # linear
+    x = torch.randn(3, 17, 512, generator=g); w = torch.randn(256, 512, generator=g) * 0.05; b = torch.randn(256, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, b); yr.square().sum().backward()
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = ops.linear(xd, wd, b.cuda()); y.square().sum().backward()
+    assert rel_err(y, yr) < 2e-5 and rel_err(xd.grad, xr.grad) < 2e-5 and rel_err(wd.grad, wr.grad) < 2e-5
+    # 3-D stem (visual_front.py:11)
+    x = torch.randn(2, 1, 6, 20, 24, generator=g); w = torch.randn(64, 1, 5, 7, 7, generator=g) * 0.05
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(x, wr, None, (1, 2, 2), (2, 3, 3))
+    gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
+    wd = w.cuda().requires_grad_(True)
+    y = ops.conv3d_stem(x.permute(0, 2, 3, 4, 1).contiguous().cuda(), wd)
+    assert rel_err(y, yr.permute(0, 2, 3, 4, 1)) < 2e-5
+    y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().cuda())
+    assert rel_err(wd.grad, wr.grad) < 2e-5

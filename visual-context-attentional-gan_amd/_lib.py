@@ -1,0 +1,83 @@
+"""ctypes binding of libvca_hip.so (the C ABI declared in include/vca_hip.h).
+
+There is no CPU fallback: importing this module without the built library raises, and every call
+checks the kernel's return code.  Build with `python __graft_entry__.py` (hipcc, gfx950).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
+SOURCES = ('conv_f32.hip',)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'vca_hip.h')]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ('N', 'D', 'Hin', 'Win', 'Cin', 'OD', 'OH', 'OW', 'Cout', 'KD', 'KH', 'KW', 'stride', 'pad_h',
+                 'pad_w', 'pad_d', 'dil', 'ups', 'act')] + [('slope', ctypes.c_float), ('out_scale', ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_SIGS = {
+    'vca_abi_version': ([], _I),
+    'vca_conv_fwd_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 10, _I),
+    'vca_conv_wgrad_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 7, _I),
+    'vca_pack_weight_f32': ([_I, _I, _I, _I, _P, _P, _F, _P], _I),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libvca_hip.so is not built (%s); run `python __graft_entry__.py`' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (what, rc))
