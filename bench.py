@@ -1,0 +1,163 @@
+"""Benchmark of the VCA-GAN hot path: one full G+D training step (forward, R1 double backward, both backward
+passes, both Adam steps) on synthetic lip-video clips.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Workload = BASELINE.json configs[1]: batch 32 per GPU, 75 frames of 96x96
+(mel 80x300, spectrogram 321x300), random-init weights, synthetic inputs already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, T, H = 32, 75, 96
+FLOP_PER_FRAME = 9.84e9          # full step at 96x96, counted on the reference with torch's FlopCounterMode
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}
+
+
+def synth(b, t, h, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    vid = torch.randn(b, 1, t, h, h, generator=g)
+    mel = torch.rand(b, 1, 80, 4 * t, generator=g) * 2 - 1
+    spec = torch.rand(b, 1, 321, 4 * t, generator=g)
+    noise = torch.randn(b, 128, 20, t, generator=g)
+    return dict(vid=vid.to(device), mel=mel.to(device), spec=spec.to(device), noise=noise.to(device),
+                vid_len=[t] * b)
+
+
+def roofline_probe(device, dtype):
+    """Time the dominant kernel (the implicit-GEMM convolution) on the step's largest layer, decode.0.conv1
+    (5x5, 640->512 on the 20x75 map of 32 clips), with HIP events on the stream it is launched on."""
+    from vcagan_amd import ops
+    x = torch.randn(B, 20, T, 640, device=device)
+    w = torch.nn.Parameter(torch.randn(512, 640, 5, 5, device=device) * 0.01)
+    bias = torch.zeros(512, device=device)
+    flops = 2.0 * B * 20 * T * 640 * 25 * 512
+    with torch.no_grad():
+        for _ in range(2):
+            ops.conv2d(x, w, bias, 1, 2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d(x, w, bias, 1, 2)
+        e1.record()
+        torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) / reps * 1e-3
+    peak = PEAK_TFLOPS[dtype]
+    ach = flops / dt / 1e12
+    return dict(bound='mfma', kernel='conv_f32_fwd_kernel<128,2,2> decode.0.conv1', achieved=round(ach, 2),
+                peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                launch_ms=round(dt * 1e3, 3), flops_per_launch=flops)
+
+
+def cpu_baseline():
+    """The CPU oracle (restatement of the reference's PyTorch CPU path) on the host cores: B2 x T75 x 112x112."""
+    from oracle import cpu_ref, fixtures
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    m = cpu_ref.build_models()
+    for k in m:
+        m[k].train()
+    opts = cpu_ref.build_optimizers(m)
+    b = fixtures.make_batch(2, 75, 112, 1)
+    cpu_ref.gan_step(m, opts, b, noise=b['noise'])
+    n = 2
+    t0 = time.time()
+    for _ in range(n):
+        cpu_ref.gan_step(m, opts, b, noise=b['noise'])
+    dt = (time.time() - t0) / n
+    return dict(value=round(2 * 75 / dt, 2), unit='frames/s', cores=cores, kind='port',
+                sample='%d full G+D steps at B2xT75x112x112 fp32 (oracle/cpu_ref.py), %.2f s/step' % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=B)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, (world, args.gpus)
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    import vcagan_amd  # noqa: F401
+    from vcagan_amd import train_step
+    torch.manual_seed(1)
+    models = train_step.build_models(device=device)
+    for k in models:
+        models[k].train()
+    if world > 1:                      # identical replicas: broadcast rank 0's initialisation
+        for k in sorted(models):
+            for t in list(models[k].parameters()) + list(models[k].buffers()):
+                dist.broadcast(t.data, 0)
+    opts = train_step.build_optimizers(models)
+    step = train_step.GanStep(models, opts, 'grid')
+    data = synth(args.batch, T, H, device, 1234 + rank)
+
+    def run(n):
+        for _ in range(n):
+            out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise=data['noise'])
+        return out
+
+    run(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out['gen_loss']).item() and torch.isfinite(out['dis_loss']).item()
+
+    if rank == 0:
+        dtype = 'fp32'
+        ms = dt / args.steps * 1e3
+        frames = args.batch * T * world
+        res = {
+            'metric': 'lip-video frames/sec (G+D fwd+bwd step) @ B32xT75x96x96 per GPU',
+            'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
+                                   'weights' % args.batch, 'global_batch': args.batch * world,
+                       'parallelism': 'dp%d' % world},
+            'step_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
+            'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
+        }
+        res['roofline'] = roofline_probe(device, dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,267 @@
+"""Generator, Postnet and discriminators (mirror of the reference's src/models/generator.py).
+
+Public tensors keep the reference's shapes (mel-spectrograms (B, 1, F, T), sentence features (B, 512, T),
+phonemes (B, T, 512)); inside a module feature maps are channels-last (B, F, T, C), which makes the
+single-channel boundary tensors free views.  nn.Conv*/nn.Linear/nn.BatchNorm* objects only hold parameters
+(same state_dict keys as the reference); the arithmetic runs through vcagan_amd.ops.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .resnet import BasicBlock
+
+_RSQRT2 = 1.0 / math.sqrt(2.0)
+
+
+def _conv(x, m, ups=0, **kw):
+    return ops.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], ups, **kw)
+
+
+class ResBlk1D(nn.Module):
+    """generator.py:8-49 (Postnet body; built without normalisation or down-sampling, :181-183)."""
+
+    def __init__(self, dim_in, dim_out, actv=None, normalize=False, downsample=False):
+        super().__init__()
+        assert not normalize and not downsample
+        self.learned_sc = dim_in != dim_out
+        self.conv1 = nn.Conv1d(dim_in, dim_in, 5, 1, 2)
+        self.conv2 = nn.Conv1d(dim_in, dim_out, 5, 1, 2)
+        if self.learned_sc:
+            self.conv1x1 = nn.Conv1d(dim_in, dim_out, 1, 1, 0, bias=False)
+
+    def forward(self, x):                                     # (B, L, C)
+        r = ops.conv1d(ops.leaky(x), self.conv1.weight, self.conv1.bias, 2)
+        r = ops.conv1d(ops.leaky(r), self.conv2.weight, self.conv2.bias, 2)
+        s = ops.conv1d(x, self.conv1x1.weight, None, 0) if self.learned_sc else x
+        return ops.add_scale(s, r, _RSQRT2)
+
+
+class ResBlk(nn.Module):
+    """generator.py:51-92 (discriminator body; built with downsample=True and no normalisation, :283)."""
+
+    def __init__(self, dim_in, dim_out, actv=None, normalize=False, downsample=False):
+        super().__init__()
+        assert not normalize
+        self.downsample = downsample
+        self.learned_sc = dim_in != dim_out
+        self.conv1 = nn.Conv2d(dim_in, dim_in, 5, 1, 2)
+        self.conv2 = nn.Conv2d(dim_in, dim_out, 5, 1, 2)
+        if self.learned_sc:
+            self.conv1x1 = nn.Conv2d(dim_in, dim_out, 1, 1, 0, bias=False)
+
+    def forward(self, x):                                     # (B, H, W, C)
+        s = _conv(x, self.conv1x1) if self.learned_sc else x
+        r = _conv(ops.leaky(x), self.conv1)
+        if self.downsample:
+            s, r = ops.avgpool2(s), ops.avgpool2(r)
+        r = _conv(ops.leaky(r), self.conv2)
+        return ops.add_scale(s, r, _RSQRT2)
+
+
+class GenResBlk(nn.Module):
+    """generator.py:94-131."""
+
+    def __init__(self, dim_in, dim_out, actv=None, upsample=False):
+        super().__init__()
+        self.upsample = upsample
+        self.learned_sc = dim_in != dim_out
+        self.conv1 = nn.Conv2d(dim_in, dim_out, 5, 1, 2)
+        self.conv2 = nn.Conv2d(dim_out, dim_out, 5, 1, 2)
+        self.norm1 = nn.BatchNorm2d(dim_in)
+        self.norm2 = nn.BatchNorm2d(dim_out)
+        if self.learned_sc:
+            self.conv1x1 = nn.Conv2d(dim_in, dim_out, 1, 1, 0, bias=False)
+
+    def forward(self, x):
+        ups = 1 if self.upsample else 0
+        r = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups)      # nearest x2 read inside the conv
+        r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
+        if self.learned_sc:
+            s = _conv(x, self.conv1x1, ups)
+        else:
+            assert not ups
+            s = x
+        return ops.add_scale(r, s, _RSQRT2)
+
+
+class Flatten(nn.Module):
+    def forward(self, input):
+        return input.view(input.size(0), -1)
+
+
+class Avgpool(nn.Module):
+    """generator.py:137-140; here over the two spatial axes of a channels-last map."""
+
+    def forward(self, input):
+        return input.mean([1, 2])
+
+
+class AVAttention(nn.Module):
+    """Visual Context Attention, generator.py:142-171."""
+
+    def __init__(self, out_dim):
+        super().__init__()
+        self.k = nn.Linear(512, out_dim)
+        self.v = nn.Linear(512, out_dim)
+        self.q = nn.Linear(2560, out_dim)
+        self.out_dim = out_dim
+        self.mel = nn.Linear(out_dim, 20 * 64)
+
+    def forward(self, ph, g, len):
+        """ph: (B, S, 512) context; g: (B, F, T, C) channels-last decoder map; len: valid context lengths.
+        Returns (B, F, T, 1280 // F) channels-last."""
+        B, Fq, T, C = g.shape
+        # query features are ordered c*F + f (generator.py:159); context features f*C' + c' (generator.py:169)
+        qin = g.permute(0, 2, 3, 1).reshape(B, T, C * Fq)
+        q = ops.linear(qin, self.q.weight, self.q.bias)
+        k = ops.linear(ph, self.k.weight, self.k.bias)
+        v = ops.linear(ph, self.v.weight, self.v.bias)
+        ctx = ops.masked_attention(q, k, v, len, 1.0 / math.sqrt(self.out_dim))
+        out = ops.linear(ctx, self.mel.weight, self.mel.bias)
+        return out.view(B, T, Fq, -1).transpose(1, 2)
+
+
+class Postnet(nn.Module):
+    """generator.py:173-192."""
+
+    def __init__(self):
+        super().__init__()
+        self.postnet = nn.Sequential(
+            nn.Conv1d(80, 128, 7, 1, 3), nn.BatchNorm1d(128), nn.LeakyReLU(0.2),
+            ResBlk1D(128, 256), ResBlk1D(256, 256), ResBlk1D(256, 256),
+            nn.Conv1d(256, 321, 1, 1, 0, bias=False))
+
+    def forward(self, x):                                      # (B, 1, 80, T)
+        p = self.postnet
+        h = x.squeeze(1).transpose(1, 2).contiguous()          # (B, T, 80)
+        h = ops.conv1d(h, p[0].weight, p[0].bias, 3)
+        h = ops.bn_act(h, p[1], ops.LEAKY)
+        h = p[5](p[4](p[3](h)))
+        h = ops.conv1d(h, p[6].weight, None, 0)                # (B, T, 321)
+        return h.transpose(1, 2).unsqueeze(1)                  # (B, 1, 321, T)
+
+
+def _to_mel(c):
+    return nn.Sequential(nn.BatchNorm2d(c), nn.LeakyReLU(0.2), nn.Conv2d(c, 1, 1, 1, 0), nn.Tanh())
+
+
+class Decoder(nn.Module):
+    """generator.py:194-265."""
+
+    def __init__(self):
+        super().__init__()
+        self.decode = nn.ModuleList()
+        self.g1 = nn.ModuleList()
+        self.g2 = nn.ModuleList()
+        self.g3 = nn.ModuleList()
+        self.att1 = AVAttention(256)
+        self.attconv1 = nn.Conv2d(128 + 64, 128, 5, 1, 2)
+        self.att2 = AVAttention(256)
+        self.attconv2 = nn.Conv2d(64 + 32, 64, 5, 1, 2)
+        self.to_mel1, self.to_mel2, self.to_mel3 = _to_mel(128), _to_mel(64), _to_mel(32)
+        self.decode.extend([GenResBlk(512 + 128, 512), GenResBlk(512, 256), GenResBlk(256, 256)])
+        self.g1.extend([GenResBlk(256, 128), GenResBlk(128, 128), GenResBlk(128, 128)])
+        self.g2.extend([GenResBlk(128, 64, upsample=True), GenResBlk(64, 64), GenResBlk(64, 64)])
+        self.g3.extend([GenResBlk(64, 32, upsample=True), GenResBlk(32, 32), GenResBlk(32, 32)])
+
+    @staticmethod
+    def _mel(head, h):
+        y = _conv(ops.bn_act(h, head[0], ops.LEAKY), head[2])          # (B, F, T, 1)
+        return ops.tanh(y).view(y.shape[0], 1, y.shape[1], y.shape[2])
+
+    def forward(self, s, x, len, noise=None):
+        """s: (B, 512, T) sentence features; x: (B, T, 512) phonemes; len: valid frames per clip.
+        noise: optional (B, 128, 20, T) tensor; by default drawn from the CPU generator like generator.py:248."""
+        B, T = x.size(0), x.size(1)
+        ctx = s.transpose(1, 2).contiguous()                             # (B, T, 512)
+        if noise is None:
+            noise = torch.randn([B, 128, 20, T])
+        noise = noise.to(x.device).permute(0, 2, 3, 1)
+        h = torch.cat([x.unsqueeze(1).expand(B, 20, T, 512), noise], 3).contiguous()   # (B, 20, T, 640)
+        for block in self.decode:
+            h = block(h)
+        for block in self.g1:
+            h = block(h)
+        g1 = h
+        h = _conv(torch.cat([h, self.att1(ctx, g1, len)], 3), self.attconv1)
+        for block in self.g2:
+            h = block(h)
+        g2 = h
+        h = _conv(torch.cat([h, self.att2(ctx, g2, len)], 3), self.attconv2)
+        for block in self.g3:
+            h = block(h)
+        return self._mel(self.to_mel1, g1), self._mel(self.to_mel2, g2), self._mel(self.to_mel3, h)
+
+
+class Discriminator(nn.Module):
+    """generator.py:267-317."""
+
+    def __init__(self, num_class=1, max_conv_dim=512, phase='1'):
+        super().__init__()
+        dim_in = 32
+        blocks = [nn.Conv2d(1, dim_in, 5, 1, 2)]
+        repeat_num = {'1': 2, '2': 3}.get(phase, 4)
+        for _ in range(repeat_num):                       # 80,4T -> 40,2T -> 20,T -> 10,T/2 -> 5,T/4
+            dim_out = min(dim_in * 2, max_conv_dim)
+            blocks.append(ResBlk(dim_in, dim_out, downsample=True))
+            dim_in = dim_out
+        self.main = nn.Sequential(*blocks)
+        self.uncond = nn.Sequential(nn.LeakyReLU(0.2), nn.Conv2d(dim_out, dim_out, 5, 1, 0), nn.LeakyReLU(0.2),
+                                    Avgpool(), nn.Linear(dim_out, num_class))
+        self.cond = nn.Sequential(nn.LeakyReLU(0.2), nn.Conv2d(dim_out + 512, dim_out, 5, 1, 2), nn.LeakyReLU(0.2),
+                                  nn.Conv2d(dim_out, dim_out, 5, 1, 0), nn.LeakyReLU(0.2),
+                                  Avgpool(), nn.Linear(dim_out, num_class))
+
+    def forward(self, x, c, vid_max_length):
+        """x: (B, 1, F, M) mel; c: (B, 512, T) sentence features.  Returns (B, 1) unconditional and conditional logits."""
+        B = x.size(0)
+        f_len = final_length(vid_max_length)
+        h = _conv(x.reshape(B, x.size(2), x.size(3), 1), self.main[0])
+        for blk in list(self.main)[1:]:
+            h = blk(h)
+        u = _conv(ops.leaky(h), self.uncond[1])
+        u = ops.linear(ops.leaky(u).mean([1, 2]), self.uncond[4].weight, self.uncond[4].bias)
+        cvec = c.mean(2)[:, None, None, :].expand(B, 5, f_len, 512)
+        o = _conv(ops.leaky(torch.cat([h, cvec], 3)), self.cond[1])
+        o = _conv(ops.leaky(o), self.cond[3])
+        o = ops.linear(ops.leaky(o).mean([1, 2]), self.cond[6].weight, self.cond[6].bias)
+        return u.view(B, -1), o.view(B, -1)
+
+
+class sync_Discriminator(nn.Module):
+    """generator.py:319-361."""
+
+    def __init__(self, temp=1.0):
+        super().__init__()
+        self.frontend = nn.Sequential(
+            nn.Conv2d(1, 128, kernel_size=(3, 3), stride=(2, 2), padding=(1, 1)), nn.BatchNorm2d(128), nn.PReLU(128),
+            nn.Conv2d(128, 256, kernel_size=(3, 3), stride=(2, 2), padding=(1, 1)), nn.BatchNorm2d(256), nn.PReLU(256))
+        self.Res_block = nn.Sequential(BasicBlock(256, 256))
+        self.Linear = nn.Linear(256 * 20, 512)
+        self.temp = temp
+
+    def forward(self, v_feat, aud, gen=False):
+        """v_feat: (B, S, 512); aud: (B, 1, 80, 4S).  Returns the per-sample loss (B,)."""
+        B = aud.size(0)
+        fe = self.frontend
+        a = _conv(aud.reshape(B, aud.size(2), aud.size(3), 1), fe[0])
+        a = ops.bn_act(a, fe[1], fe[2])
+        a = ops.bn_act(_conv(a, fe[3]), fe[4], fe[5])
+        a = self.Res_block(a)                                             # (B, 20, S, 256)
+        b, f, t, ch = a.shape
+        a = a.permute(0, 2, 3, 1).reshape(b, t, ch * f)                   # feature index c*F + f (generator.py:344)
+        a = ops.linear(a, self.Linear.weight, self.Linear.bias)          # (B, S, 512)
+        return ops.sync_loss(v_feat, a, self.temp, gen)
+
+
+def gan_loss(inputs, label=None):
+    """generator.py:363-366."""
+    return ops.softplus_mean(inputs, -1.0 if label else 1.0)
+
+
+def final_length(vid_length):
+    """generator.py:368-371."""
+    return (vid_length // 2) // 2

@@ -1,0 +1,32 @@
+"""Visual front-end (mirror of the reference's src/models/visual_front.py:4-37)."""
+import torch.nn as nn
+
+from .. import ops
+from .resnet import BasicBlock, ResNet
+
+
+class Visual_front(nn.Module):
+    def __init__(self, in_channels=1):
+        super().__init__()
+        assert in_channels == 1, 'the lip crops are single-channel (visual_front.py:11, vid_aud_grid.py:104-111)'
+        self.in_channels = in_channels
+        self.frontend = nn.Sequential(
+            nn.Conv3d(in_channels, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            nn.BatchNorm3d(64), nn.PReLU(64),
+            nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
+        self.resnet = ResNet(BasicBlock, [2, 2, 2, 2], relu_type='prelu')
+        self.dropout = nn.Dropout(0.3)
+        self.sentence_encoder = nn.GRU(512, 512, 2, bidirectional=True, dropout=0.3)
+        self.fc = nn.Linear(1024, 512)
+
+    def forward(self, x):
+        """x: (B, 1, T, H, W) video.  Returns phonemes (B, T, 512) and sentence features (B, 512, T)."""
+        B, _, T, H, W = x.shape
+        f = ops.conv3d_stem(x.reshape(B, T, H, W, 1), self.frontend[0].weight)       # (B,T,H/2,W/2,64)
+        f = ops.bn_act(f, self.frontend[1], self.frontend[2])
+        f = ops.maxpool3x3s2(f.view(B * T, f.shape[2], f.shape[3], 64))              # frames flattened for free
+        f = self.resnet(f)                                                           # (B*T, 512)
+        f = self.dropout(f).view(B, T, 512)
+        sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)
+        sent = ops.linear(sent, self.fc.weight, self.fc.bias)                        # (B, T, 512)
+        return f, sent.transpose(1, 2).contiguous()

@@ -22,7 +22,7 @@ ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 # --------------------------------------------------------------------------- #
 # weight packing
 # --------------------------------------------------------------------------- #
-_pack_cache = weakref.WeakKeyDictionary()
+_pack_cache = {}     # id(parameter) -> (weakref, {mode: (version, packed tensor)})
 
 
 def _wdims(w):
@@ -38,15 +38,20 @@ def _pack(w, mode):
     cout, cin, taps = _wdims(w)
     cacheable = isinstance(w, torch.nn.Parameter)
     if cacheable:
-        ent = _pack_cache.get(w)
-        if ent is not None and ent.get(mode, (None,))[0] == w._version:
-            return ent[mode][1]
+        ent = _pack_cache.get(id(w))
+        if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == w._version:
+            return ent[1][mode][1]
     wd = w.detach().contiguous()
     row = ((cout + 3) // 4 * 4) if mode == 0 else ((cin + 3) // 4 * 4)
     out = torch.empty((taps, cin if mode == 0 else cout, row), device=w.device, dtype=torch.float32)
     check(_lib.lib().vca_pack_weight_f32(mode, cout, cin, taps, ptr(wd), ptr(out), 0.0, stream()), 'pack_weight')
     if cacheable:
-        _pack_cache.setdefault(w, {})[mode] = (w._version, out)
+        key = id(w)
+        ent = _pack_cache.get(key)
+        if ent is None or ent[0]() is not w:
+            ent = (weakref.ref(w, lambda _r, key=key: _pack_cache.pop(key, None)), {})
+            _pack_cache[key] = ent
+        ent[1][mode] = (w._version, out)
     return out
 
 
@@ -202,3 +207,100 @@ def conv3d_stem(x, w, stride=2, pad=(2, 3, 3)):
     """x: (N,D,H,W,1); w: (Cout,1,KD,KH,KW), spatial stride `stride`, temporal stride 1 (visual_front.py:11)."""
     cfg = ConvCfg(w.shape, x.shape, stride, (pad[1], pad[2]), 0, pad_d=pad[0])
     return ConvFn.apply(x, w, None, cfg)
+
+
+# --------------------------------------------------------------------------- #
+# per-channel / pointwise / pooling / recurrent / loss operators
+# --------------------------------------------------------------------------- #
+LEAKY = 'leaky0.2'      # the generator/discriminator activation (generator.py:9,52,95: nn.LeakyReLU(0.2))
+
+
+def _act(y, act):
+    F = torch.nn.functional
+    if act is None:
+        return y
+    if act == LEAKY:
+        return F.leaky_relu(y, 0.2)
+    if isinstance(act, torch.nn.PReLU):
+        return torch.where(y > 0, y, y * act.weight)
+    if isinstance(act, torch.nn.ReLU):
+        return F.relu(y)
+    raise ValueError(act)
+
+
+def bn_act(x, bn, act=None, residual=None):
+    """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor."""
+    C = x.shape[-1]
+    y = torch.nn.functional.batch_norm(x.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                       bn.training, bn.momentum, bn.eps).view(x.shape)
+    if bn.training:
+        bn.num_batches_tracked += 1
+    if residual is not None:
+        y = y + residual
+    return _act(y, act)
+
+
+def leaky(x):
+    return torch.nn.functional.leaky_relu(x, 0.2)
+
+
+def tanh(x):
+    return torch.tanh(x)
+
+
+def add_scale(a, b, scale):
+    return (a + b) * scale
+
+
+def avgpool2(x):
+    """F.avg_pool2d(x, 2) on a channels-last map (floor on odd sizes)."""
+    n, h, w, c = x.shape
+    h2, w2 = h // 2, w // 2
+    return x[:, :h2 * 2, :w2 * 2].reshape(n, h2, 2, w2, 2, c).mean((2, 4))
+
+
+def maxpool3x3s2(x):
+    """MaxPool (3x3, stride 2, pad 1) on a channels-last map (visual_front.py:14)."""
+    y = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def head_pool4(x):
+    """nn.AvgPool2d(4) of resnet.py:82 on a channels-last map whose output is 1x1: the mean of the top-left 4x4
+    window when the map is at least 4 wide, the global mean otherwise (96x96 / 48x48 clips)."""
+    n, h, w, c = x.shape
+    if h >= 4 and w >= 4:
+        assert h < 8 and w < 8, 'AvgPool2d(4) output must be 1x1 (visual_front.py:30)'
+        return x[:, :4, :4].mean((1, 2))
+    return x.mean((1, 2))
+
+
+def gru(x, mod, training):
+    """x: (B, T, 512) -> (B, T, 1024); 2-layer bidirectional GRU (visual_front.py:20,33-34)."""
+    out, _ = mod(x.transpose(0, 1).contiguous())
+    return out.transpose(0, 1)
+
+
+def masked_attention(q, k, v, lens, scale):
+    """softmax(q k^T * scale, keys >= lens[b] masked) v   (generator.py:161-167)."""
+    att = torch.bmm(q, k.transpose(1, 2)) * scale
+    S = att.shape[2]
+    lens_t = torch.as_tensor([int(l) for l in lens], device=att.device)
+    pad = torch.arange(S, device=att.device)[None, None, :] >= lens_t[:, None, None]
+    att = att.masked_fill(pad, float('-inf')).softmax(2)
+    return torch.bmm(att, v)
+
+
+def sync_loss(v_feat, a_feat, temp, gen):
+    """generator.py:347-361."""
+    F = torch.nn.functional
+    if gen:
+        return 5.0 - F.cosine_similarity(v_feat, a_feat, 2).abs().mean(1)
+    sim = torch.bmm(F.normalize(v_feat, dim=2), F.normalize(a_feat, dim=2).transpose(1, 2)) / temp
+    d_va = torch.diagonal(F.log_softmax(sim, 2), dim1=-2, dim2=-1).mean(1)
+    d_av = torch.diagonal(F.log_softmax(sim, 1), dim1=-2, dim2=-1).mean(1)
+    return -0.5 * (d_va + d_av)
+
+
+def softplus_mean(x, sign):
+    return torch.nn.functional.softplus(sign * x).mean()

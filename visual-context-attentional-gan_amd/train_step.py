@@ -1,0 +1,156 @@
+"""One GAN training step (host-side mirror of the loop body of the reference's train.py:166-237 and
+train_LRS.py:179-243) plus the data-parallel gradient exchange.
+
+The reference parallelises with nn.DataParallel (train.py:112-119): one process, weights re-broadcast on every
+module call, gradients reduced onto GPU 0.  Here each GPU is its own process holding a full replica; a step
+does its local forward/backward on the local shard of the batch and exchanges gradients twice with RCCL
+all-reduce (mean): the discriminator-side gradients before d_optimizer.step(), and the generator-side
+gradients (which for v_front include the sync-loss contribution of the D phase) before g_optimizer.step().
+Batch-norm statistics stay per replica, as they do under DataParallel.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .models import generator as G
+from .models.visual_front import Visual_front
+
+G_NAMES = ('v_front', 'gen', 'post')
+D_NAMES = ('dis1', 'dis2', 'dis3', 's_dis')
+_LOG_EPS = math.log(1e-5)
+
+
+def build_models(temp=1.0, device=None):
+    """The seven networks of train.py:70-76."""
+    m = dict(v_front=Visual_front(in_channels=1), gen=G.Decoder(), post=G.Postnet(),
+             dis1=G.Discriminator(phase='1'), dis2=G.Discriminator(phase='2'), dis3=G.Discriminator(phase='3'),
+             s_dis=G.sync_Discriminator(temp=temp))
+    if device is not None:
+        for k in m:
+            m[k].to(device)
+    return m
+
+
+def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
+    """train.py:78-83 (GRID, amsgrad) / train_LRS.py:94-98 (no amsgrad)."""
+    g = torch.optim.Adam([{'params': models[n].parameters()} for n in G_NAMES], lr=lr, weight_decay=weight_decay,
+                         amsgrad=amsgrad)
+    d = torch.optim.Adam([{'params': models[n].parameters()} for n in D_NAMES], lr=lr, weight_decay=weight_decay,
+                         amsgrad=amsgrad)
+    return g, d
+
+
+def denormalize(m):
+    """Log-mel de-normalisation of src/data/vid_aud_grid.py:238-240."""
+    return (m + 1.0) * (-_LOG_EPS / 2.0) + _LOG_EPS
+
+
+class GradExchange:
+    """Bucketed mean all-reduce of a fixed parameter list (one flat fp32 buffer per bucket)."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in params:
+            if not p.requires_grad:
+                continue
+            nb = p.numel() * 4
+            if cur and cur_bytes + nb > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [None] * len(self.buckets)
+
+    def reduce(self):
+        if self.world == 1:
+            return
+        works = []
+        for i, bucket in enumerate(self.buckets):
+            ps = [p for p in bucket if p.grad is not None]
+            if not ps:
+                continue
+            n = sum(p.numel() for p in ps)
+            if self.flat[i] is None or self.flat[i].numel() != n:
+                self.flat[i] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+            flat = self.flat[i]
+            torch._foreach_copy_(list(flat.split([p.numel() for p in ps])), [p.grad.reshape(-1) for p in ps])
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, ps))
+        for work, flat, ps in works:
+            work.wait()
+            flat.mul_(1.0 / self.world)
+            torch._foreach_copy_([p.grad.reshape(-1) for p in ps], list(flat.split([p.numel() for p in ps])))
+
+
+class GanStep:
+    """Callable running one full G+D step; variant 'grid' = train.py, 'lrs' = train_LRS.py."""
+
+    def __init__(self, models, optimizers, variant='grid', group=None):
+        self.m = models
+        self.g_opt, self.d_opt = optimizers
+        self.variant = variant
+        self.d_exchange = GradExchange([p for n in D_NAMES for p in models[n].parameters()], group=group)
+        self.g_exchange = GradExchange([p for n in G_NAMES for p in models[n].parameters()], group=group)
+
+    def __call__(self, mel, spec, vid, vid_len, noise=None):
+        """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths."""
+        m = self.m
+        for n in G_NAMES:
+            m[n].zero_grad(set_to_none=True)
+        mel1 = F.interpolate(mel, scale_factor=0.25, mode='bilinear', align_corners=False)
+        mel2 = F.interpolate(mel, scale_factor=0.5, mode='bilinear', align_corners=False)
+        phon, sent = m['v_front'](vid)
+        g1, g2, g3 = m['gen'](sent, phon, vid_len, noise=noise)
+        reals = [t.detach().clone().requires_grad_(True) for t in (mel1, mel2, mel)]
+        T = phon.size(1)
+        sd = sent.detach()
+        dis = (m['dis1'], m['dis2'], m['dis3'])
+
+        # ---- discriminator phase (train.py:182-211)
+        real_lo = [d(r, sd, T) for d, r in zip(dis, reals)]
+        sync_loss = m['s_dis'](phon, reals[2]).mean()
+        grad_p = []
+        for (u, _), r in zip(real_lo, reals):
+            gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
+            grad_p.append(gr.reshape(gr.size(0), -1).pow(2).sum(1).mean())
+        fake_lo = [d(g.detach(), sd, T) for d, g in zip(dis, (g1, g2, g3))]
+        real_loss = (sum(G.gan_loss(u, True) for u, _ in real_lo)
+                     + sum(G.gan_loss(c, True) for _, c in real_lo)) / 3 + sum(grad_p) / 3
+        fake_loss = (sum(G.gan_loss(u, False) for u, _ in fake_lo)
+                     + sum(G.gan_loss(c, False) for _, c in fake_lo)) / 3
+        dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
+        self.d_opt.zero_grad(set_to_none=True)
+        dis_loss.backward(retain_graph=True)          # also accumulates the sync-loss gradient into v_front
+        self.d_exchange.reduce()
+        self.d_opt.step()
+
+        # ---- generator phase (train.py:215-237)
+        gs = m['post'](g3)
+        gen_lo = [d(g, sd, T) for d, g in zip(dis, (g1, g2, g3))]
+        g_sync = m['s_dis'](phon.detach(), g3, gen=True).mean()
+        g_adv = (sum(G.gan_loss(u, True) for u, _ in gen_lo) + sum(G.gan_loss(c, True) for _, c in gen_lo)) / 3
+        tgt = [r.detach() for r in reals]
+        if self.variant == 'grid':
+            g_loss = g_adv + g_sync
+            recon = sum(F.l1_loss(denormalize(g), denormalize(t)) for g, t in zip((g1, g2, g3), tgt)) / 3 \
+                + F.l1_loss(gs, spec)
+            gen_loss = g_loss + 50.0 * recon
+        else:
+            g_loss = g_adv
+            recon = sum(F.l1_loss(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + F.l1_loss(gs, spec)
+            gen_loss = g_loss + 50.0 * recon + g_sync
+        for n in D_NAMES + ('gen', 'post'):
+            m[n].zero_grad(set_to_none=True)
+        gen_loss.backward()
+        self.g_exchange.reduce()
+        self.g_opt.step()
+        return dict(dis_loss=dis_loss.detach(), gen_loss=gen_loss.detach(), sync_loss=sync_loss.detach(),
+                    g_sync_loss=g_sync.detach(), recon_loss=recon.detach(), g_loss=g_loss.detach(),
+                    grad_p=torch.stack([x.detach() for x in grad_p]),
+                    g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
