@@ -76,6 +76,66 @@ int vca_conv_wgrad_f32(const vca_conv_desc* d, const float* x, const float* gy,
 int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const float* src, float* dst, float beta,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-channel kernels on a channels-last matrix view x[P][C] (C % 4 == 0).
+ * Replace nn.BatchNorm1d/2d/3d (train and eval), nn.PReLU / nn.LeakyReLU / nn.ReLU / nn.Tanh, the
+ * residual adds and the 1/sqrt(2) scaling at: visual_front.py:12-13, resnet.py:34-64,
+ * generator.py:22-49,77-92,105-131,179-180,208-225,325-333.
+ * ---------------------------------------------------------------------------------------------- */
+/* sums[0..C) += sum_p (x[p][c] - x[0][c]);  sums[C..2C) += sum_p (x[p][c] - x[0][c])^2   (caller zeroes) */
+int vca_colstats_f32(int P, int C, const float* x, float* sums, void* stream);
+
+/* Train-mode statistics -> mean, 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale; updates the
+ * running statistics in place (momentum, unbiased variance) when running_mean/var are given.
+ * `sums` as written by vca_colstats_f32 or the convolution epilogue; `pivot` is what was subtracted (or NULL). */
+int vca_bn_finalize_f32(int C, float count, const float* sums, const float* pivot, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* Eval-mode coefficients from the running statistics. */
+int vca_bn_eval_coeff_f32(int C, const float* running_mean, const float* running_var, const float* gamma,
+                          const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift,
+                          void* stream);
+
+/* y = act(x*scale + shift + res) * oscale.  act: 0 none, 1 LeakyReLU(slope), 2 PReLU(alpha[c]), 3 ReLU, 4 tanh;
+ * scale/shift, alpha and res may be NULL. */
+int vca_affine_act_f32(int P, int C, const float* x, const float* scale, const float* shift, const float* alpha,
+                       const float* res, int act, float slope, float oscale, float* y, void* stream);
+
+/* Backward of vca_affine_act_f32.  With gz = gy*oscale*act'(z):
+ *   sums (3*C, zeroed by the caller; may be NULL when train == 0 and act != PReLU) receives
+ *     sum gz, sum gz*xhat (xhat = (x-mean)*invstd) and sum gy*oscale*min(z,0)  = d beta, d gamma, d alpha;
+ *   gx   = scale*(gz - mean(gz) - xhat*mean(gz*xhat)) when train != 0 (batch statistics), scale*gz otherwise;
+ *   gres = gz.   gx / gres may be NULL. */
+int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const float* scale, const float* shift,
+                           const float* alpha, const float* res, const float* mean, const float* invstd, int act,
+                           float slope, float oscale, int train, float* sums, float* gx, float* gres, void* stream);
+
+/* 2x2 pooling family on [N][H][W][C] (F.avg_pool2d(x,2) generator.py:74,83; nearest x2 upsample :112,121).
+ * (Hs,Ws) is the small map, (Hl,Wl) the large one, Hs = Hl/2, Ws = Wl/2.
+ * mode 0: average large->small; 1: its adjoint small->large; 2: block sum large->small; 3: nearest upsample. */
+int vca_pool2_f32(int mode, int N, int Hs, int Ws, int Hl, int Wl, int C, const float* x, float* y, void* stream);
+
+/* MaxPool (3x3, stride 2, pad 1) of visual_front.py:14 (per frame), forward (+argmax tap) and backward. */
+int vca_maxpool3s2_fwd_f32(int N, int H, int W, int C, const float* x, float* y, unsigned char* idx, void* stream);
+int vca_maxpool3s2_bwd_f32(int N, int H, int W, int C, const float* gy, const unsigned char* idx, float* gx,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses and optimiser.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[0] += scale * sum softplus(sign*x)  and its backward (gan_loss, generator.py:363-366). */
+int vca_softplus_sum_f32(int n, const float* x, float sign, float scale, float* out, void* stream);
+int vca_softplus_bwd_f32(int n, const float* x, float sign, float scale, const float* gout, float* gx, void* stream);
+/* out[0] += scale * sum |a - b|  and d/da (nn.L1Loss, train.py:150,226-229). */
+int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, float* out, void* stream);
+int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
+                   void* stream);
+/* torch.optim.Adam step (coupled L2 weight decay; amsgrad when vmax != NULL) over a flat buffer, n % 4 == 0
+ * (train.py:82-83,211,237). `step` is the 1-based step count. */
+int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,164 @@
+"""Per-channel / pooling / loss / Adam HIP kernels (through the C ABI) vs torch CPU operators.  fp32; tolerance 1e-5
+relative to the tensor's max magnitude unless noted."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return (a.detach().cpu().double() - b.detach().double()).abs().max().item() / (b.detach().abs().max().item() + 1e-12)
+
+
+@gpu
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('act', ['prelu', 'leaky', 'relu', None])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn_act(train, act, with_res):
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(1)
+    N, H, W, C = 3, 7, 5, 64
+    x = torch.randn(N, H, W, C, generator=g) * 2 + 0.5
+    res = torch.randn(N, H, W, C, generator=g) if with_res else None
+    gy = torch.randn(N, H, W, C, generator=g)
+
+    def mk():
+        bn = nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(2)) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(3)))
+            bn.running_mean.copy_(torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5)
+        a = None
+        if act == 'prelu':
+            a = nn.PReLU(C)
+            with torch.no_grad():
+                a.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(6)) * 0.5)
+        elif act == 'relu':
+            a = nn.ReLU()
+        return bn.train(train), a
+
+    bn_r, a_r = mk()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    rr = res.permute(0, 3, 1, 2).clone().requires_grad_(True) if with_res else None
+    yr = bn_r(xr)
+    if with_res:
+        yr = yr + rr
+    yr = F.leaky_relu(yr, 0.2) if act == 'leaky' else (a_r(yr) if a_r is not None else yr)
+    yr.backward(gy.permute(0, 3, 1, 2))
+
+    bn_d, a_d = mk()
+    bn_d.cuda()
+    if isinstance(a_d, nn.PReLU):
+        a_d.cuda()
+    xd = x.cuda().requires_grad_(True)
+    rd = res.cuda().requires_grad_(True) if with_res else None
+    y = ops.bn_act(xd, bn_d, ops.LEAKY if act == 'leaky' else a_d, rd)
+    y.backward(gy.cuda())
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 1e-5
+    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 2e-5
+    assert rel_err(bn_d.weight.grad, bn_r.weight.grad) < 2e-5
+    assert rel_err(bn_d.bias.grad, bn_r.bias.grad) < 2e-5
+    if with_res:
+        assert rel_err(rd.grad, rr.grad.permute(0, 2, 3, 1)) < 1e-5
+    if act == 'prelu':
+        assert rel_err(a_d.weight.grad, a_r.weight.grad) < 2e-5
+    assert rel_err(bn_d.running_mean, bn_r.running_mean) < 1e-5
+    assert rel_err(bn_d.running_var, bn_r.running_var) < 1e-5
+    assert int(bn_d.num_batches_tracked) == int(bn_r.num_batches_tracked)
+
+
+@gpu
+def test_wide_and_1d_bn():
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for shape in [(2, 20, 9, 640), (3, 50, 128), (1000, 1280)]:
+        C = shape[-1]
+        x = torch.randn(*shape, generator=g) + 1.0
+        bn = nn.BatchNorm1d(C).train()
+        ref = bn(x.reshape(-1, C)).reshape(shape)
+        bn2 = nn.BatchNorm1d(C).train().cuda()
+        y = ops.bn_act(x.cuda(), bn2, None)
+        assert rel_err(y, ref) < 1e-5
+
+
+@gpu
+def test_act_double_backward_and_pools():
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 9, 6, 32, generator=g)
+    w = torch.randn(2, 4, 3, 32, generator=g)
+
+    def f(leaky, pool, xx):
+        h = pool(leaky(xx))
+        out = (h * h * w.to(h.device)).sum()
+        gr, = torch.autograd.grad(out, xx, create_graph=True)
+        return (gr ** 2).sum() + out
+
+    xr = x.clone().requires_grad_(True)
+    pr = f(lambda t: F.leaky_relu(t, 0.2),
+           lambda t: F.avg_pool2d(t.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), xr)
+    pr.backward()
+    xd = x.cuda().requires_grad_(True)
+    pd = f(ops.leaky, ops.avgpool2, xd)
+    pd.backward()
+    assert abs(pd.item() - pr.item()) < 1e-5 * abs(pr.item())
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    # max pool 3x3 s2 p1
+    x = torch.randn(3, 11, 12, 64, generator=g)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.cuda().requires_grad_(True)
+    y = ops.maxpool3x3s2(xd)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) == 0
+    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 1e-6
+    # residual merge and tanh on a single-channel map
+    a, b = torch.randn(2, 5, 4, 32, generator=g), torch.randn(2, 5, 4, 32, generator=g)
+    ad, bd = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.add_scale(ad, bd, 0.70710678)
+    y.sum().backward()
+    assert rel_err(y, (a + b) * 0.70710678) < 1e-6 and rel_err(ad.grad, torch.full_like(a, 0.70710678)) < 1e-6
+    t = torch.randn(2, 20, 10, 1, generator=g)
+    td = t.cuda().requires_grad_(True)
+    y = ops.tanh(td)
+    y.sum().backward()
+    assert rel_err(y, torch.tanh(t)) < 1e-6 and rel_err(td.grad, 1 - torch.tanh(t) ** 2) < 1e-5
+
+
+@gpu
+def test_losses_and_adam():
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 1, generator=g) * 3
+    for sign in (1.0, -1.0):
+        xr = x.clone().requires_grad_(True)
+        lr_ = F.softplus(sign * xr).mean(); lr_.backward()
+        xd = x.cuda().requires_grad_(True)
+        ld = ops.softplus_mean(xd, sign); ld.backward()
+        assert abs(ld.item() - lr_.item()) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-5
+    a, b = torch.randn(2, 1, 80, 40, generator=g), torch.randn(2, 1, 80, 40, generator=g)
+    ar = a.clone().requires_grad_(True)
+    lr_ = F.l1_loss(ar * 5.7 + 1, b * 5.7 + 1); lr_.backward()
+    ad = a.cuda().requires_grad_(True)
+    ld = ops.l1_mean(ad, b.cuda(), 5.7); ld.backward()
+    assert abs(ld.item() - lr_.item()) < 1e-5 * lr_.item() and rel_err(ad.grad, ar.grad) < 1e-5
+    # fused Adam (amsgrad on/off) against torch.optim.Adam for 3 steps
+    for ams in (True, False):
+        lin_r = nn.Sequential(nn.Linear(37, 19), nn.Linear(19, 5))
+        lin_d = nn.Sequential(nn.Linear(37, 19), nn.Linear(19, 5))
+        lin_d.load_state_dict(lin_r.state_dict())
+        lin_d.cuda()
+        opt_r = torch.optim.Adam(lin_r.parameters(), lr=1e-2, weight_decay=1e-3, amsgrad=ams)
+        flat = ops.flatten_module(lin_d)
+        opt_d = ops.FusedAdam([flat], lr=1e-2, weight_decay=1e-3, amsgrad=ams)
+        for it in range(3):
+            xin = torch.randn(11, 37, generator=g)
+            opt_r.zero_grad(); lin_r(xin).square().sum().backward(); opt_r.step()
+            opt_d.zero_grad(); lin_d(xin.cuda()).square().sum().backward(); opt_d.step()
+        for pr, pd in zip(lin_r.parameters(), lin_d.parameters()):
+            assert rel_err(pd, pr) < 1e-5

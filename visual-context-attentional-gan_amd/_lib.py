@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
-SOURCES = ('conv_f32.hip',)
+SOURCES = ('conv_f32.hip', 'pointwise.hip', 'misc.hip')
 
 
 def build(force=False, verbose=False):
@@ -39,11 +39,25 @@ class ConvDesc(ctypes.Structure):
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_LL = ctypes.c_longlong
 _SIGS = {
     'vca_abi_version': ([], _I),
     'vca_conv_fwd_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 10, _I),
     'vca_conv_wgrad_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 7, _I),
     'vca_pack_weight_f32': ([_I, _I, _I, _I, _P, _P, _F, _P], _I),
+    'vca_colstats_f32': ([_I, _I, _P, _P, _P], _I),
+    'vca_bn_finalize_f32': ([_I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
+    'vca_affine_act_f32': ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P], _I),
+    'vca_affine_act_bwd_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I, _P, _P, _P, _P], _I),
+    'vca_pool2_f32': ([_I] * 7 + [_P, _P, _P], _I),
+    'vca_maxpool3s2_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P], _I),
+    'vca_maxpool3s2_bwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P], _I),
+    'vca_softplus_sum_f32': ([_I, _P, _F, _F, _P, _P], _I),
+    'vca_softplus_bwd_f32': ([_I, _P, _F, _F, _P, _P, _P], _I),
+    'vca_l1_sum_f32': ([_LL, _P, _P, _F, _P, _P], _I),
+    'vca_l1_bwd_f32': ([_LL, _P, _P, _F, _P, _P, _P], _I),
+    'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P], _I),
 }
 
 _lib = None

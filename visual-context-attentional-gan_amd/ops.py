@@ -22,6 +22,7 @@ ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 # --------------------------------------------------------------------------- #
 # weight packing
 # --------------------------------------------------------------------------- #
+_param_epoch = [0]   # bumped whenever parameters are rewritten behind autograd's back (fused Adam, re-homing)
 _pack_cache = {}     # id(parameter) -> (weakref, {mode: (version, packed tensor)})
 
 
@@ -39,7 +40,7 @@ def _pack(w, mode):
     cacheable = isinstance(w, torch.nn.Parameter)
     if cacheable:
         ent = _pack_cache.get(id(w))
-        if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == w._version:
+        if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == (w._version, _param_epoch[0]):
             return ent[1][mode][1]
     wd = w.detach().contiguous()
     row = ((cout + 3) // 4 * 4) if mode == 0 else ((cin + 3) // 4 * 4)
@@ -51,7 +52,7 @@ def _pack(w, mode):
         if ent is None or ent[0]() is not w:
             ent = (weakref.ref(w, lambda _r, key=key: _pack_cache.pop(key, None)), {})
             _pack_cache[key] = ent
-        ent[1][mode] = (w._version, out)
+        ent[1][mode] = ((w._version, _param_epoch[0]), out)
     return out
 
 
@@ -210,59 +211,264 @@ def conv3d_stem(x, w, stride=2, pad=(2, 3, 3)):
 
 
 # --------------------------------------------------------------------------- #
-# per-channel / pointwise / pooling / recurrent / loss operators
+# per-channel kernels: batch-norm + activation, activations, residual scale-add
 # --------------------------------------------------------------------------- #
 LEAKY = 'leaky0.2'      # the generator/discriminator activation (generator.py:9,52,95: nn.LeakyReLU(0.2))
+once = torch.autograd.function.once_differentiable
 
 
-def _act(y, act):
-    F = torch.nn.functional
+def _act_code(act):
+    """-> (code, slope, alpha tensor or None)"""
     if act is None:
-        return y
+        return ACT_NONE, 0.0, None
     if act == LEAKY:
-        return F.leaky_relu(y, 0.2)
+        return ACT_LEAKY, 0.2, None
+    if act == 'tanh':
+        return ACT_TANH, 0.0, None
     if isinstance(act, torch.nn.PReLU):
-        return torch.where(y > 0, y, y * act.weight)
+        return ACT_PRELU, 0.0, act.weight
     if isinstance(act, torch.nn.ReLU):
-        return F.relu(y)
+        return ACT_RELU, 0.0, None
+    if isinstance(act, torch.nn.LeakyReLU):
+        return ACT_LEAKY, float(act.negative_slope), None
     raise ValueError(act)
+
+
+def _pc(x):
+    c = x.shape[-1]
+    return x.numel() // c, c
+
+
+class BnActFn(torch.autograd.Function):
+    """y = act(x*scale + shift + res) * oscale with (scale, shift) from batch-norm coefficients `coef`
+    (rows: mean, invstd, scale, shift) or absent; gradients for x, gamma, beta, alpha, res."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, res, coef, act, slope, oscale, train):
+        x = _c(x)
+        res = _c(res) if res is not None else None
+        P, C = _pc(x)
+        y = torch.empty_like(x)
+        sc, sh = (coef[2], coef[3]) if coef is not None else (None, None)
+        check(_lib.lib().vca_affine_act_f32(P, C, ptr(x), ptr(sc), ptr(sh), ptr(alpha), ptr(res), act, slope, oscale,
+                                            ptr(y), stream()), 'affine_act')
+        ctx.save_for_backward(x, alpha, res, coef)
+        ctx.cfg = (act, slope, oscale, train, gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        x, alpha, res, coef = ctx.saved_tensors
+        act, slope, oscale, train, has_g, has_b = ctx.cfg
+        P, C = _pc(x)
+        gy = _c(gy)
+        need_sums = coef is not None or act == ACT_PRELU
+        sums = torch.zeros((3, C), device=x.device, dtype=torch.float32) if need_sums else None
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
+        mean, invstd, sc, sh = (coef[0], coef[1], coef[2], coef[3]) if coef is not None else (None,) * 4
+        check(_lib.lib().vca_affine_act_bwd_f32(P, C, ptr(gy), ptr(x), ptr(sc), ptr(sh), ptr(alpha), ptr(res),
+                                                ptr(mean), ptr(invstd), act, slope, oscale, 1 if train else 0,
+                                                ptr(sums), ptr(gx), ptr(gres), stream()), 'affine_act_bwd')
+        ggamma = sums[1] if (coef is not None and has_g) else None
+        gbeta = sums[0] if (coef is not None and has_b) else None
+        galpha = sums[2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
+        return gx, ggamma, gbeta, galpha, gres, None, None, None, None, None
+
+
+def _bn_coef(x, bn):
+    """Batch-norm coefficients (mean, invstd, scale, shift) for a channels-last tensor; updates running stats."""
+    P, C = _pc(x)
+    coef = torch.empty((4, C), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    if bn.training or bn.running_mean is None:
+        sums = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+        xd = _c(x.detach())
+        check(L.vca_colstats_f32(P, C, ptr(xd), ptr(sums), stream()), 'colstats')
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        check(L.vca_bn_finalize_f32(C, float(P), ptr(sums), ptr(xd), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                    bn.eps, mom, ptr(bn.running_mean) if track else None,
+                                    ptr(bn.running_var) if track else None,
+                                    ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
+        if track:
+            bn.num_batches_tracked += 1
+        return coef, True
+    check(L.vca_bn_eval_coeff_f32(C, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.weight.detach()),
+                                  ptr(bn.bias.detach()), bn.eps, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
+                                  ptr(coef[3]), stream()), 'bn_eval_coeff')
+    return coef, False
 
 
 def bn_act(x, bn, act=None, residual=None):
     """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor."""
-    C = x.shape[-1]
-    y = torch.nn.functional.batch_norm(x.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                       bn.training, bn.momentum, bn.eps).view(x.shape)
-    if bn.training:
-        bn.num_batches_tracked += 1
-    if residual is not None:
-        y = y + residual
-    return _act(y, act)
+    code, slope, alpha = _act_code(act)
+    coef, train = _bn_coef(x, bn)
+    return BnActFn.apply(x, bn.weight, bn.bias, alpha, residual, coef, code, slope, 1.0, train)
+
+
+class ActFn(torch.autograd.Function):
+    """Parameter-free activation with a differentiable backward (the discriminators' R1 path needs it)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _c(x)
+        P, C = _pc(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().vca_affine_act_f32(P, C, ptr(x), None, None, None, None, act, slope, 1.0, ptr(y), stream()),
+              'act')
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        return ActBwdFn.apply(gy, x, *ctx.cfg), None, None
+
+
+class ActBwdFn(torch.autograd.Function):
+    """gx = gy * act'(x): linear in gy, so its own backward is the same operator."""
+
+    @staticmethod
+    def forward(ctx, gy, x, act, slope):
+        gy = _c(gy)
+        P, C = _pc(x)
+        gx = torch.empty_like(x)
+        check(_lib.lib().vca_affine_act_bwd_f32(P, C, ptr(gy), ptr(x), None, None, None, None, None, None, act, slope,
+                                                1.0, 0, None, ptr(gx), None, stream()), 'act_bwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, slope)
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        x, = ctx.saved_tensors
+        return ActBwdFn.apply(ggx, x, *ctx.cfg), None, None, None
+
+
+def _pad4(x):
+    """Views whose channel count is not a multiple of 4 (single-channel mel maps) are processed as flat rows."""
+    c = x.shape[-1]
+    if c % 4 == 0:
+        return x, None
+    n = x.numel()
+    assert n % 4 == 0, x.shape
+    return x.reshape(-1, 4), x.shape
 
 
 def leaky(x):
-    return torch.nn.functional.leaky_relu(x, 0.2)
+    return ActFn.apply(x, ACT_LEAKY, 0.2)
 
 
 def tanh(x):
-    return torch.tanh(x)
+    x2, shp = _pad4(x)
+    y = BnActFn.apply(x2, None, None, None, None, None, ACT_TANH, 0.0, 1.0, False)
+    return y if shp is None else y.view(shp)
+
+
+class ScaleFn(torch.autograd.Function):
+    """y = x * scale (linear, so its backward is itself)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x2, shp = _pad4(_c(x))
+        P, C = _pc(x2)
+        y = torch.empty_like(x2)
+        check(_lib.lib().vca_affine_act_f32(P, C, ptr(x2), None, None, None, None, ACT_NONE, 0.0, scale, ptr(y),
+                                            stream()), 'scale')
+        ctx.scale = scale
+        return y if shp is None else y.view(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ScaleFn.apply(g, ctx.scale), None
+
+
+class AddScaleFn(torch.autograd.Function):
+    """y = (a + b) * scale with a differentiable backward (the discriminator blocks sit on the R1 path)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = _c(a), _c(b)
+        P, C = _pc(a)
+        y = torch.empty_like(a)
+        check(_lib.lib().vca_affine_act_f32(P, C, ptr(a), None, None, None, ptr(b), ACT_NONE, 0.0, scale, ptr(y),
+                                            stream()), 'add_scale')
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ScaleFn.apply(g, ctx.scale)
+        return gs, gs, None
 
 
 def add_scale(a, b, scale):
-    return (a + b) * scale
+    """(a + b) * scale  (the residual merge of generator.py:49,92,130)."""
+    return AddScaleFn.apply(a, b, scale)
+
+
+# --------------------------------------------------------------------------- #
+# pooling
+# --------------------------------------------------------------------------- #
+def _pool2_raw(mode, x, small_hw, large_hw):
+    n, c = x.shape[0], x.shape[-1]
+    (hs, ws), (hl, wl) = small_hw, large_hw
+    out_hw = small_hw if mode in (0, 2) else large_hw
+    y = torch.empty((n,) + tuple(out_hw) + (c,), device=x.device, dtype=torch.float32)
+    check(_lib.lib().vca_pool2_f32(mode, n, hs, ws, hl, wl, c, ptr(_c(x)), ptr(y), stream()), 'pool2')
+    return y
+
+
+class Pool2Fn(torch.autograd.Function):
+    """modes 0/1 (average and its adjoint) and 2/3 (block sum and nearest upsample) are adjoint pairs."""
+
+    @staticmethod
+    def forward(ctx, x, mode, small_hw, large_hw):
+        ctx.cfg = (mode, small_hw, large_hw)
+        return _pool2_raw(mode, x, small_hw, large_hw)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mode, small_hw, large_hw = ctx.cfg
+        return Pool2Fn.apply(gy, mode ^ 1, small_hw, large_hw), None, None, None
 
 
 def avgpool2(x):
     """F.avg_pool2d(x, 2) on a channels-last map (floor on odd sizes)."""
     n, h, w, c = x.shape
-    h2, w2 = h // 2, w // 2
-    return x[:, :h2 * 2, :w2 * 2].reshape(n, h2, 2, w2, 2, c).mean((2, 4))
+    return Pool2Fn.apply(x, 0, (h // 2, w // 2), (h, w))
+
+
+class MaxPool3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        n, h, w, c = x.shape
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        check(_lib.lib().vca_maxpool3s2_fwd_f32(n, h, w, c, ptr(x), ptr(y), idx.data_ptr(), stream()), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        idx, = ctx.saved_tensors
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
+        check(_lib.lib().vca_maxpool3s2_bwd_f32(n, h, w, c, ptr(_c(gy)), idx.data_ptr(), ptr(gx), stream()),
+              'maxpool_bwd')
+        return gx
 
 
 def maxpool3x3s2(x):
     """MaxPool (3x3, stride 2, pad 1) on a channels-last map (visual_front.py:14)."""
-    y = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1)
-    return y.permute(0, 2, 3, 1).contiguous()
+    return MaxPool3Fn.apply(x)
 
 
 def head_pool4(x):
@@ -275,6 +481,65 @@ def head_pool4(x):
     return x.mean((1, 2))
 
 
+# --------------------------------------------------------------------------- #
+# losses
+# --------------------------------------------------------------------------- #
+class SoftplusMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sign):
+        x = _c(x)
+        out = torch.zeros((), device=x.device, dtype=torch.float32)
+        n = x.numel()
+        check(_lib.lib().vca_softplus_sum_f32(n, ptr(x), sign, 1.0 / n, ptr(out), stream()), 'softplus_sum')
+        ctx.save_for_backward(x)
+        ctx.sign = sign
+        return out
+
+    @staticmethod
+    @once
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        n = x.numel()
+        check(_lib.lib().vca_softplus_bwd_f32(n, ptr(x), ctx.sign, 1.0 / n, ptr(_c(g)), ptr(gx), stream()),
+              'softplus_bwd')
+        return gx, None
+
+
+def softplus_mean(x, sign):
+    """mean(softplus(sign * x))  (gan_loss, generator.py:363-366)."""
+    return SoftplusMeanFn.apply(x, float(sign))
+
+
+class L1MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mul):
+        a, b = _c(a), _c(b)
+        out = torch.zeros((), device=a.device, dtype=torch.float32)
+        n = a.numel()
+        ctx.scale = abs(mul) / n
+        check(_lib.lib().vca_l1_sum_f32(n, ptr(a), ptr(b), ctx.scale, ptr(out), stream()), 'l1_sum')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    @once
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        check(_lib.lib().vca_l1_bwd_f32(a.numel(), ptr(a), ptr(b), ctx.scale, ptr(_c(g)), ptr(ga), stream()), 'l1_bwd')
+        return ga, None, None
+
+
+def l1_mean(a, b, mul=1.0):
+    """mean |mul*a - mul*b| with the gradient flowing to `a` only (nn.L1Loss of an affine map of both arguments:
+    the mel de-normalisation of vid_aud_grid.py:238-240 has slope `mul`)."""
+    return L1MeanFn.apply(a, b.detach(), float(mul))
+
+
+# --------------------------------------------------------------------------- #
+# recurrent / attention / sync loss (torch operators; HIP kernels replace them one by one)
+# --------------------------------------------------------------------------- #
 def gru(x, mod, training):
     """x: (B, T, 512) -> (B, T, 1024); 2-layer bidirectional GRU (visual_front.py:20,33-34)."""
     out, _ = mod(x.transpose(0, 1).contiguous())
@@ -302,5 +567,50 @@ def sync_loss(v_feat, a_feat, temp, gen):
     return -0.5 * (d_va + d_av)
 
 
-def softplus_mean(x, sign):
-    return torch.nn.functional.softplus(sign * x).mean()
+# --------------------------------------------------------------------------- #
+# flat parameter storage + fused Adam
+# --------------------------------------------------------------------------- #
+def flatten_module(module):
+    """Re-home every parameter of `module` (already on its device) into one flat fp32 buffer and give it a flat,
+    persistent gradient buffer: p.data and p.grad become views.  Returns (flat_params, flat_grads)."""
+    ps = [p for p in module.parameters()]
+    sizes = [(p.numel() + 3) // 4 * 4 for p in ps]
+    total = sum(sizes)
+    dev = ps[0].device
+    flat = torch.zeros(total, device=dev, dtype=torch.float32)
+    gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+    off = 0
+    for p, sz in zip(ps, sizes):
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        p.grad = gflat[off:off + n].view(p.shape)
+        off += sz
+    _param_epoch[0] += 1
+    return flat, gflat
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (coupled L2 weight decay, optional amsgrad; train.py:82-83) as one kernel launch
+    per flat buffer.  `groups` is a list of (flat_params, flat_grads) from flatten_module."""
+
+    def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        self.groups = groups
+        self.lr, self.betas, self.eps, self.weight_decay, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
+        self.param_groups = [dict(lr=lr)]       # the reference reads param_groups[0]['lr'] for logging
+        self.t = 0
+        self.state = [dict(m=torch.zeros_like(f), v=torch.zeros_like(f),
+                           vmax=torch.zeros_like(f) if amsgrad else None) for f, _ in groups]
+
+    def zero_grad(self, set_to_none=False):
+        for _, g in self.groups:
+            g.zero_()
+
+    def step(self):
+        self.t += 1
+        lr = self.param_groups[0]['lr']
+        for (f, g), st in zip(self.groups, self.state):
+            check(_lib.lib().vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
+                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                          stream()), 'adam')
+        _param_epoch[0] += 1

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import ops
 from .models import generator as G
 from .models.visual_front import Visual_front
 
@@ -34,11 +35,15 @@ def build_models(temp=1.0, device=None):
 
 
 def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
-    """train.py:78-83 (GRID, amsgrad) / train_LRS.py:94-98 (no amsgrad)."""
-    g = torch.optim.Adam([{'params': models[n].parameters()} for n in G_NAMES], lr=lr, weight_decay=weight_decay,
-                         amsgrad=amsgrad)
-    d = torch.optim.Adam([{'params': models[n].parameters()} for n in D_NAMES], lr=lr, weight_decay=weight_decay,
-                         amsgrad=amsgrad)
+    """train.py:78-83 (GRID, amsgrad) / train_LRS.py:94-98 (no amsgrad): one Adam over (v_front, gen, post) and one
+    over (dis1, dis2, dis3, s_dis).  Each module's parameters are re-homed into one flat buffer with a persistent
+    flat gradient, so an optimizer step is one kernel per module and a gradient exchange is one all-reduce per
+    module with no packing copies.  Call after the modules are on their device."""
+    flats = {n: ops.flatten_module(models[n]) for n in G_NAMES + D_NAMES}
+    g = ops.FusedAdam([flats[n] for n in G_NAMES], lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+    d = ops.FusedAdam([flats[n] for n in D_NAMES], lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+    g.flats = {n: flats[n] for n in G_NAMES}
+    d.flats = {n: flats[n] for n in D_NAMES}
     return g, d
 
 
@@ -48,44 +53,20 @@ def denormalize(m):
 
 
 class GradExchange:
-    """Bucketed mean all-reduce of a fixed parameter list (one flat fp32 buffer per bucket)."""
+    """Mean all-reduce of flat gradient buffers (one RCCL call per module, issued back to back and waited together)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+    def __init__(self, gflats, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.buckets = []
-        cur, cur_bytes = [], 0
-        for p in params:
-            if not p.requires_grad:
-                continue
-            nb = p.numel() * 4
-            if cur and cur_bytes + nb > bucket_bytes:
-                self.buckets.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nb
-        if cur:
-            self.buckets.append(cur)
-        self.flat = [None] * len(self.buckets)
+        self.gflats = list(gflats)
 
     def reduce(self):
         if self.world == 1:
             return
-        works = []
-        for i, bucket in enumerate(self.buckets):
-            ps = [p for p in bucket if p.grad is not None]
-            if not ps:
-                continue
-            n = sum(p.numel() for p in ps)
-            if self.flat[i] is None or self.flat[i].numel() != n:
-                self.flat[i] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
-            flat = self.flat[i]
-            torch._foreach_copy_(list(flat.split([p.numel() for p in ps])), [p.grad.reshape(-1) for p in ps])
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, ps))
-        for work, flat, ps in works:
-            work.wait()
-            flat.mul_(1.0 / self.world)
-            torch._foreach_copy_([p.grad.reshape(-1) for p in ps], list(flat.split([p.numel() for p in ps])))
+        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for g in self.gflats]
+        for w, g in zip(works, self.gflats):
+            w.wait()
+            g.mul_(1.0 / self.world)
 
 
 class GanStep:
@@ -95,14 +76,18 @@ class GanStep:
         self.m = models
         self.g_opt, self.d_opt = optimizers
         self.variant = variant
-        self.d_exchange = GradExchange([p for n in D_NAMES for p in models[n].parameters()], group=group)
-        self.g_exchange = GradExchange([p for n in G_NAMES for p in models[n].parameters()], group=group)
+        self.gflat = {n: gf for opt in optimizers for n, (_, gf) in opt.flats.items()}
+        self.d_exchange = GradExchange([self.gflat[n] for n in D_NAMES], group=group)
+        self.g_exchange = GradExchange([self.gflat[n] for n in G_NAMES], group=group)
+
+    def _zero(self, names):
+        for n in names:
+            self.gflat[n].zero_()
 
     def __call__(self, mel, spec, vid, vid_len, noise=None):
         """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths."""
         m = self.m
-        for n in G_NAMES:
-            m[n].zero_grad(set_to_none=True)
+        self._zero(G_NAMES)
         mel1 = F.interpolate(mel, scale_factor=0.25, mode='bilinear', align_corners=False)
         mel2 = F.interpolate(mel, scale_factor=0.5, mode='bilinear', align_corners=False)
         phon, sent = m['v_front'](vid)
@@ -125,7 +110,7 @@ class GanStep:
         fake_loss = (sum(G.gan_loss(u, False) for u, _ in fake_lo)
                      + sum(G.gan_loss(c, False) for _, c in fake_lo)) / 3
         dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
-        self.d_opt.zero_grad(set_to_none=True)
+        self._zero(D_NAMES)
         dis_loss.backward(retain_graph=True)          # also accumulates the sync-loss gradient into v_front
         self.d_exchange.reduce()
         self.d_opt.step()
@@ -138,15 +123,14 @@ class GanStep:
         tgt = [r.detach() for r in reals]
         if self.variant == 'grid':
             g_loss = g_adv + g_sync
-            recon = sum(F.l1_loss(denormalize(g), denormalize(t)) for g, t in zip((g1, g2, g3), tgt)) / 3 \
-                + F.l1_loss(gs, spec)
+            k = -_LOG_EPS / 2.0           # slope of the de-normalisation applied to both L1 arguments
+            recon = sum(ops.l1_mean(g, t, k) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, spec)
             gen_loss = g_loss + 50.0 * recon
         else:
             g_loss = g_adv
-            recon = sum(F.l1_loss(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + F.l1_loss(gs, spec)
+            recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, spec)
             gen_loss = g_loss + 50.0 * recon + g_sync
-        for n in D_NAMES + ('gen', 'post'):
-            m[n].zero_grad(set_to_none=True)
+        self._zero(D_NAMES + ('gen', 'post'))
         gen_loss.backward()
         self.g_exchange.reduce()
         self.g_opt.step()
