@@ -22,7 +22,8 @@ if ROOT not in sys.path:
 
 B, T, H = 32, 75, 96
 FLOP_PER_FRAME = 9.84e9          # full step at 96x96, counted on the reference with torch's FlopCounterMode
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0}
+MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3}
 
 
 def synth(b, t, h, device, seed):
@@ -56,10 +57,13 @@ def roofline_probe(device, dtype):
         torch.cuda.synchronize()
     dt = e0.elapsed_time(e1) / reps * 1e-3
     peak = PEAK_TFLOPS[dtype]
-    ach = flops / dt / 1e12
-    return dict(bound='mfma', kernel='conv_f32_fwd_kernel<128,2,2> decode.0.conv1', achieved=round(ach, 2),
-                peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                launch_ms=round(dt * 1e3, 3), flops_per_launch=flops)
+    ach = flops / dt / 1e12                         # algorithmic (fp32-equivalent) rate
+    issued = ach * MFMA_PER_PRODUCT[dtype]          # matrix-core work actually issued (3 bf16 MFMAs per product)
+    kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else 'conv_bf16_halo_kernel<128,2,2,%d>' % MFMA_PER_PRODUCT[dtype]
+    return dict(bound='mfma', kernel=kern + ' on decode.0.conv1', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
+                frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
+                issued_frac=round(issued / peak, 4), traffic=None, launch_ms=round(dt * 1e3, 3),
+                flops_per_launch=flops)
 
 
 def cpu_baseline():
@@ -89,6 +93,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=B)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
+    ap.add_argument('--precision', default='bf16x3', choices=['fp32', 'bf16x3', 'bf16'])
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -101,7 +107,8 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     import vcagan_amd  # noqa: F401
-    from vcagan_amd import train_step
+    from vcagan_amd import ops, train_step
+    ops.set_precision(args.precision)
     torch.manual_seed(1)
     models = train_step.build_models(device=device)
     for k in models:
@@ -114,9 +121,23 @@ def main():
     step = train_step.GanStep(models, opts, 'grid')
     data = synth(args.batch, T, H, device, 1234 + rank)
 
+    graphed = None
+    if not args.no_graph:
+        try:
+            graphed = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'],
+                                             data['noise'])
+        except Exception as e:       # capture not possible on this stack: fall back to eager launches
+            print('graph capture failed, running eagerly: %r' % (e,), file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
+
     def run(n):
+        out = None
         for _ in range(n):
-            out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise=data['noise'])
+            if graphed is not None:
+                out = graphed(data['mel'], data['spec'], data['vid'], None, data['noise'])
+            else:
+                out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise=data['noise'])
         return out
 
     run(args.warmup)
@@ -136,14 +157,14 @@ def main():
     assert torch.isfinite(out['gen_loss']).item() and torch.isfinite(out['dis_loss']).item()
 
     if rank == 0:
-        dtype = 'fp32'
+        dtype = args.precision
         ms = dt / args.steps * 1e3
         frames = args.batch * T * world
         res = {
             'metric': 'lip-video frames/sec (G+D fwd+bwd step) @ B32xT75x96x96 per GPU',
             'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic', 'launch': 'hip-graph' if graphed is not None else 'eager',
             'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                    'weights' % args.batch, 'global_batch': args.batch * world,
                        'parallelism': 'dp%d' % world},

@@ -76,6 +76,21 @@ int vca_conv_wgrad_f32(const vca_conv_desc* d, const float* x, const float* gy,
 int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const float* src, float* dst, float beta,
                         void* stream);
 
+/* Split-bf16 variant of vca_conv_fwd_f32 on v_mfma_f32_32x32x16_bf16 (2-D maps, Cin > 1; used for the
+ * forward pass and, with the input-gradient descriptor, for the input gradient).  nsplit = 3: every fp32
+ * operand is split into bf16 hi + lo and hi*hi + hi*lo + lo*hi is accumulated in fp32; nsplit = 1: plain
+ * bf16 operands.  wpack is the layout written by vca_pack_weight_bf16 (mode 0 forward, 1 input gradient),
+ * vca_pack_weight_bf16_bytes gives its size. */
+int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack, const float* bias,
+                      const float* in_scale, const float* in_shift, const float* in_alpha, const float* res,
+                      float* y, float* stats, void* stream);
+/* Split-bf16 variant of vca_conv_wgrad_f32 (same fp32 [tap][Cin][Cout4] output, accumulated with atomics into a
+ * zeroed buffer; at most 32 taps). */
+int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, const float* gy, const float* in_scale,
+                        const float* in_shift, const float* in_alpha, float* dwpack, void* stream);
+long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps);
+int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-channel kernels on a channels-last matrix view x[P][C] (C % 4 == 0).
  * Replace nn.BatchNorm1d/2d/3d (train and eval), nn.PReLU / nn.LeakyReLU / nn.ReLU / nn.Tanh, the
@@ -132,9 +147,10 @@ int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, flo
 int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
                    void* stream);
 /* torch.optim.Adam step (coupled L2 weight decay; amsgrad when vmax != NULL) over a flat buffer, n % 4 == 0
- * (train.py:82-83,211,237). `step` is the 1-based step count. */
+ * (train.py:82-83,211,237). `step` is the 1-based step count; when step_dev != NULL the count is read from that
+ * device word instead (so the launch can be replayed from a captured HIP graph). */
 int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int step, void* stream);
+                 float beta2, float eps, float weight_decay, int step, const int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,10 +28,34 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _reset_precision():
+    yield
+    try:
+        from vcagan_amd import ops
+        ops.set_precision('fp32')
+    except Exception:
+        pass
+
+
+BIG_CASES = [
+    (2, 20, 75, 64, 128, 5, 1, 2, 0),      # decoder-shaped map: 5x25 patches
+    (5, 24, 24, 64, 64, 3, 1, 1, 0),       # ResNet layer1
+    (30, 6, 6, 128, 256, 3, 1, 1, 0),      # small maps: several images per patch
+    (40, 3, 3, 256, 512, 3, 1, 1, 0),
+    (9, 12, 12, 64, 128, 3, 2, 1, 0),
+    (2, 40, 30, 32, 32, 5, 1, 2, 1),
+    (3, 5, 18, 160, 128, 5, 1, 0, 0),
+    (200, 1, 1, 512, 96, 1, 1, 0, 0),      # linear layer
+]
+
+
 @gpu
-@pytest.mark.parametrize('case', CASES)
-def test_conv2d_fwd_bwd(case):
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-5), ('bf16x3', 1e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('case', CASES + BIG_CASES)
+def test_conv2d_fwd_bwd(case, prec, tol):
     from vcagan_amd import ops
+    ops.set_precision(prec)
     N, H, W, Cin, Cout, K, s, p, ups = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, H, W, Cin, generator=g)
@@ -47,10 +71,10 @@ def test_conv2d_fwd_bwd(case):
     xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
     y = ops.conv2d(xd, wd, bd, s, p, ups)
     assert y.shape == (N,) + tuple(yr.shape[2:]) + (Cout,)
-    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 2e-5
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < tol
     y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
-    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 2e-5
-    assert rel_err(wd.grad, wr.grad) < 2e-5
+    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+    assert rel_err(wd.grad, wr.grad) < tol
     assert rel_err(bd.grad, br.grad) < 2e-5
 
 

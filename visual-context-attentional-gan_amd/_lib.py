@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
-SOURCES = ('conv_f32.hip', 'pointwise.hip', 'misc.hip')
+SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip')
 
 
 def build(force=False, verbose=False):
@@ -45,6 +45,10 @@ _SIGS = {
     'vca_conv_fwd_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 10, _I),
     'vca_conv_wgrad_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 7, _I),
     'vca_pack_weight_f32': ([_I, _I, _I, _I, _P, _P, _F, _P], _I),
+    'vca_conv_fwd_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10, _I),
+    'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 7, _I),
+    'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
+    'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_colstats_f32': ([_I, _I, _P, _P, _P], _I),
     'vca_bn_finalize_f32': ([_I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
@@ -57,7 +61,7 @@ _SIGS = {
     'vca_softplus_bwd_f32': ([_I, _P, _F, _F, _P, _P, _P], _I),
     'vca_l1_sum_f32': ([_LL, _P, _P, _F, _P, _P], _I),
     'vca_l1_bwd_f32': ([_LL, _P, _P, _F, _P, _P, _P], _I),
-    'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P], _I),
+    'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 
 _lib = None

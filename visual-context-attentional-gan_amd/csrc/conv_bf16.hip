@@ -1,0 +1,680 @@
+// Split-bf16 implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (forward / input gradient).
+//
+// Precision: every fp32 operand v is split as v = hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is
+// accumulated in fp32 as hi*hi + hi*lo + lo*hi ("bf16x3", ~2^-17 relative error per product, which keeps the
+// generated mel-spectrograms within 1e-4 of the fp32 reference; a single bf16 product does not: 2e-2).
+// NSPLIT = 1 computes hi*hi only.
+//
+// Tiling: a workgroup owns a patch of NI images x TH x TW output pixels (<= 128 rows of the GEMM) and BN output
+// channels.  For each slice of 32 input channels the input HALO of the patch ((TH-1)*stride+KH) x
+// ((TW-1)*stride+KW) positions is staged in LDS once (fp32 -> prologue -> hi/lo bf16) and reused by every
+// filter tap: the A fragment of tap (kh,kw) is the same LDS image read at a shifted position, so activation
+// traffic from L2 does not scale with the number of taps.  The weights of one (tap, slice) are streamed through
+// a double-buffered LDS tile.  LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with
+// (row >> 2) & 3 so that ds_read_b128 of 16 consecutive rows is conflict-free.
+#include <mutex>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128;
+constexpr int MAXPOS = 384;  // halo positions per workgroup (hi + lo images: 48 KiB)
+
+struct HArgs {
+  vca_conv_desc d;
+  const float* x;
+  const unsigned char* w;  // packed [tap][chunk][npad][hi 32 | lo 32] bf16
+  const float* bias;
+  const float* in_scale;
+  const float* in_shift;
+  const float* in_alpha;
+  const float* res;
+  float* y;
+  float* stats;
+  int npad, nchunk, ntaps;
+  int NI, TH, TW, HH, HW, NPOS;
+  int tiles_x, tiles_y;
+  int vecA;
+};
+
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = (__bf16)v[j];
+    l[j] = (__bf16)(v[j] - (float)h[j]);
+  }
+  hi = *reinterpret_cast<uint4*>(&h);
+  lo = *reinterpret_cast<uint4*>(&l);
+}
+
+template <int BN, int WM, int WN, int NSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int BROW = (NSPLIT == 3) ? 128 : 64;  // bytes of one packed weight row that are used
+  constexpr int BBUF = BN * BROW;                 // bytes of one weight LDS buffer
+  constexpr int NBP = (BN * (BROW / 16) + 255) / 256;
+
+  const vca_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int npos_total = a.NI * a.NPOS;
+  unsigned char* halo_hi = smem;
+  unsigned char* halo_lo = smem + npos_total * 64;
+  unsigned char* bbase = smem + npos_total * 64 * (NSPLIT == 3 ? 2 : 1);
+
+  int bx = blockIdx.x;
+  const int tix = bx % a.tiles_x; bx /= a.tiles_x;
+  const int tiy = bx % a.tiles_y;
+  const int tin = bx / a.tiles_y;
+  const int nb = tin * a.NI, oy0 = tiy * a.TH, ox0 = tix * a.TW;
+  const int n0 = blockIdx.y * BN;
+  const int He = d.Hin << d.ups, We = d.Win << d.ups;
+  const int tpix = a.TH * a.TW;
+
+  // halo base position of this lane's MT accumulator rows
+  int hb[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = wm * WTM + i * 32 + lr;
+    const int img = m / tpix, rem = m - img * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    hb[i] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 rbw[NBP];
+  auto issue_b = [&](int tap, int chunk) {
+    const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad + n0) * 128;
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      const int q = tid + i * 256;
+      rbw[i] = make_uint4(0, 0, 0, 0);
+      if (q < BN * (BROW / 16)) {
+        const int row = q / (BROW / 16), c = q - row * (BROW / 16);
+        if (n0 + row < a.npad) rbw[i] = *reinterpret_cast<const uint4*>(src + row * 128 + c * 16);
+      }
+    }
+  };
+  auto commit_b = [&](int buf) {
+    unsigned char* dst = bbase + buf * BBUF;
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      const int q = tid + i * 256;
+      if (q < BN * (BROW / 16)) {
+        const int row = q / (BROW / 16), c = q - row * (BROW / 16);
+        const int part = c >> 2, cc = c & 3;  // part 0 = hi image, 1 = lo image
+        *reinterpret_cast<uint4*>(dst + part * (BN * 64) + row * 64 + ((cc ^ ((row >> 2) & 3)) << 4)) = rbw[i];
+      }
+    }
+  };
+
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
+    // ---- stage the halo of this 32-channel slice
+    for (int it = tid; it < npos_total * 2; it += 256) {
+      const int pos = it >> 1, half = it & 1;
+      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
+      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
+      const int n = nb + img;
+      bool ok = n < d.N && vy >= 0 && vx >= 0;
+      if (d.dil > 1) {
+        ok = ok && (vy % d.dil == 0) && (vx % d.dil == 0);
+        vy /= d.dil;
+        vx /= d.dil;
+      }
+      ok = ok && vy < He && vx < We;
+      vy >>= d.ups;
+      vx >>= d.ups;
+      const int ci0 = chunk * 32 + half * 16;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = 0.f;
+      if (ok && ci0 < d.Cin) {
+        const float* src = a.x + ((size_t)(n * d.Hin + vy) * d.Win + vx) * d.Cin + ci0;
+        if (a.vecA && ci0 + 16 <= d.Cin) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (ci0 + j < d.Cin) v[j] = src[j];
+        }
+        if (a.in_scale || d.act) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ci = ci0 + j;
+            if (ci < d.Cin) {
+              float z = v[j];
+              if (a.in_scale) z = z * a.in_scale[ci] + a.in_shift[ci];
+              if (d.act) z = vca_act(z, d.act, d.act == VCA_ACT_PRELU ? a.in_alpha[ci] : d.slope);
+              v[j] = z;
+            }
+          }
+        }
+      }
+      const int sw = (pos >> 2) & 3;
+      uint4 h0, l0, h1, l1;
+      split8(v, h0, l0);
+      split8(v + 8, h1, l1);
+      unsigned char* ph = halo_hi + pos * 64;
+      *reinterpret_cast<uint4*>(ph + (((2 * half) ^ sw) << 4)) = h0;
+      *reinterpret_cast<uint4*>(ph + (((2 * half + 1) ^ sw) << 4)) = h1;
+      if (NSPLIT == 3) {
+        unsigned char* pl = halo_lo + pos * 64;
+        *reinterpret_cast<uint4*>(pl + (((2 * half) ^ sw) << 4)) = l0;
+        *reinterpret_cast<uint4*>(pl + (((2 * half + 1) ^ sw) << 4)) = l1;
+      }
+    }
+    issue_b(0, chunk);
+    commit_b(0);
+    __syncthreads();
+
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int buf = tap & 1;
+      if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk);
+      const int kh = tap / d.KW, kw = tap - kh * d.KW;
+      const int tapoff = kh * a.HW + kw;
+      const unsigned char* bh_base = bbase + buf * BBUF;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + lh;
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int pa = hb[i] + tapoff;
+          const int off = pa * 64 + ((c ^ ((pa >> 2) & 3)) << 4);
+          ah[i] = *reinterpret_cast<const bf16x8*>(halo_hi + off);
+          if (NSPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(halo_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * WTN + j * 32 + lr;
+          const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+          bh[j] = *reinterpret_cast<const bf16x8*>(bh_base + off);
+          if (NSPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bh_base + BN * 64 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (NSPLIT == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      if (tap + 1 < a.ntaps) commit_b(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + lr;
+    const bool nv = n < d.Cout;
+    const float b = (nv && a.bias) ? a.bias[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int img = m / tpix, rem = m - img * tpix;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        const int nn = nb + img, oy = oy0 + ty, ox = ox0 + tx;
+        if (nv && img < a.NI && nn < d.N && oy < d.OH && ox < d.OW) {
+          float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+          v += b;
+          const size_t o = ((size_t)(nn * d.OH + oy) * d.OW + ox) * d.Cout + n;
+          if (a.res) v += a.res[o];
+          a.y[o] = v * d.out_scale;
+        }
+      }
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (nv && lh == 0) {
+        atomicAdd(a.stats + n, s1);
+        atomicAdd(a.stats + d.Cout + n, s2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient (split-bf16)
+//
+// dW[tap][ci][co] = sum over output pixels of xin[pixel (+) tap][ci] * gy[pixel][co].  A workgroup owns a
+// 32 x 32 (ci x co) tile of EVERY tap and walks patches of 128 output pixels (the reduction): per patch it stages
+// the input halo [position][32 ci] and the output-gradient tile [pixel][32 co] in LDS as hi/lo bf16, and the MFMA
+// operands (which need 8 consecutive reduction indices per lane) are fetched with the transposing LDS read
+// ds_read_b64_tr_b16: 4 rows (pixels) x 16 columns (channels) per 16-lane group, delivered column-major.  The
+// taps are dealt round-robin to the 8 waves (each keeps its taps' accumulators in registers for the whole walk);
+// a 1-tap convolution instead splits the patch's pixels across the waves.  Partial tiles are added to dW with
+// fp32 atomics (pixels are also split across workgroups).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WArgs {
+  vca_conv_desc d;
+  const float* x;
+  const float* gy;
+  const float* in_scale;
+  const float* in_shift;
+  const float* in_alpha;
+  float* dw;  // fp32 [tap][Cin][Cout4]
+  int Cout4, ntaps;
+  int NI, TH, TW, HH, HW, NPOS;
+  int tiles_x, tiles_y, ntiles, tiles_per_block, co_tiles;
+  int vecA, vecB;
+};
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  // two transposed reads: reduction rows kbase..kbase+3 and kbase+4..kbase+7 of this lane's column
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAXSLOT = 4;  // taps per wave (25 taps / 8 waves)
+  constexpr int NW = 8;
+  const vca_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npos_total = a.NI * a.NPOS;
+  unsigned char* halo_hi = smem;
+  unsigned char* halo_lo = halo_hi + npos_total * 64;
+  unsigned char* gy_hi = halo_lo + (NSPLIT == 3 ? npos_total * 64 : 0);
+  unsigned char* gy_lo = gy_hi + BM * 64;
+
+  const int cot = blockIdx.x % a.co_tiles, cit = blockIdx.x / a.co_tiles;
+  const int ci_base = cit * 32, co_base = cot * 32;
+  const int He = d.Hin << d.ups, We = d.Win << d.ups;
+  const int tpix = a.TH * a.TW;
+  const bool one_tap = a.ntaps == 1;
+
+  // transposed-read geometry of this lane: column (channel) group and reduction-row offsets
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int col = 16 * (g & 1) + 4 * p;       // first of the 4 channels this lane addresses
+  const int kq = 8 * (g >> 1) + q;            // reduction row this lane addresses within a 16-deep MFMA step
+  const int colchunk = col >> 3, colbyte = (col & 7) * 2;
+  int pk[16];                                 // halo position of reduction row k = (s>>1)*16 + kq + 4*(s&1)
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = (s >> 1) * 16 + kq + 4 * (s & 1);
+    const int img = k / tpix, rem = k - img * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    pk[s] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
+  }
+
+  f32x16 acc[MAXSLOT];
+#pragma unroll
+  for (int t = 0; t < MAXSLOT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int pt_beg = blockIdx.y * a.tiles_per_block;
+  const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
+  for (int pt = pt_beg; pt < pt_end; ++pt) {
+    int bx = pt;
+    const int tix = bx % a.tiles_x; bx /= a.tiles_x;
+    const int tiy = bx % a.tiles_y;
+    const int tin = bx / a.tiles_y;
+    const int nb = tin * a.NI, oy0 = tiy * a.TH, ox0 = tix * a.TW;
+    __syncthreads();
+    // ---- input halo of this patch, channels ci_base .. ci_base+31
+    for (int it = tid; it < npos_total * 2; it += 512) {
+      const int pos = it >> 1, half = it & 1;
+      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
+      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
+      const int n = nb + img;
+      const bool ok = n < d.N && vy >= 0 && vx >= 0 && vy < He && vx < We;
+      vy >>= d.ups;
+      vx >>= d.ups;
+      const int ci0 = ci_base + half * 16;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = 0.f;
+      if (ok && ci0 < d.Cin) {
+        const float* src = a.x + ((size_t)(n * d.Hin + vy) * d.Win + vx) * d.Cin + ci0;
+        if (a.vecA && ci0 + 16 <= d.Cin) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const float4 t = *reinterpret_cast<const float4*>(src + 4 * qq);
+            v[4 * qq] = t.x; v[4 * qq + 1] = t.y; v[4 * qq + 2] = t.z; v[4 * qq + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (ci0 + j < d.Cin) v[j] = src[j];
+        }
+        if (a.in_scale || d.act) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ci = ci0 + j;
+            if (ci < d.Cin) {
+              float z = v[j];
+              if (a.in_scale) z = z * a.in_scale[ci] + a.in_shift[ci];
+              if (d.act) z = vca_act(z, d.act, d.act == VCA_ACT_PRELU ? a.in_alpha[ci] : d.slope);
+              v[j] = z;
+            }
+          }
+        }
+      }
+      const int sw = (pos >> 2) & 3;
+      uint4 h0, l0, h1, l1;
+      split8(v, h0, l0);
+      split8(v + 8, h1, l1);
+      *reinterpret_cast<uint4*>(halo_hi + pos * 64 + (((2 * half) ^ sw) << 4)) = h0;
+      *reinterpret_cast<uint4*>(halo_hi + pos * 64 + (((2 * half + 1) ^ sw) << 4)) = h1;
+      if (NSPLIT == 3) {
+        *reinterpret_cast<uint4*>(halo_lo + pos * 64 + (((2 * half) ^ sw) << 4)) = l0;
+        *reinterpret_cast<uint4*>(halo_lo + pos * 64 + (((2 * half + 1) ^ sw) << 4)) = l1;
+      }
+    }
+    // ---- output-gradient tile [128 pixels][32 co]: 4 threads per pixel, 8 channels each
+    {
+      const int m = tid >> 2, qt = tid & 3;
+      const int img = m / tpix, rem = m - img * tpix;
+      const int ty = rem / a.TW, tx = rem - ty * a.TW;
+      const int n = nb + img, oy = oy0 + ty, ox = ox0 + tx;
+      const int c0 = co_base + qt * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (img < a.NI && n < d.N && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+        const float* src = a.gy + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.Cout + c0;
+        if (a.vecB && c0 + 8 <= d.Cout) {
+          const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
+          v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j < d.Cout) v[j] = src[j];
+        }
+      }
+      const int sw = (m >> 2) & 3;
+      uint4 h0, l0;
+      split8(v, h0, l0);
+      *reinterpret_cast<uint4*>(gy_hi + m * 64 + ((qt ^ sw) << 4)) = h0;
+      if (NSPLIT == 3) *reinterpret_cast<uint4*>(gy_lo + m * 64 + ((qt ^ sw) << 4)) = l0;
+    }
+    __syncthreads();
+
+    // ---- two halves of the patch (64 pixels each): the B fragments (output gradient) of a half stay in
+    //      registers while every tap of this wave sweeps it
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x8 bh[4], bl[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k0 = (hf * 4 + kk) * 16 + kq, k1 = k0 + 4;
+        const int o0 = k0 * 64 + ((colchunk ^ ((k0 >> 2) & 3)) << 4) + colbyte;
+        const int o1 = k1 * 64 + ((colchunk ^ ((k1 >> 2) & 3)) << 4) + colbyte;
+        bh[kk] = tr_read8(gy_hi + o0, gy_hi + o1);
+        if (NSPLIT == 3) bl[kk] = tr_read8(gy_lo + o0, gy_lo + o1);
+      }
+#pragma unroll
+      for (int ts = 0; ts < MAXSLOT; ++ts) {
+        const int tap = one_tap ? 0 : wave + NW * ts;
+        if (tap < a.ntaps && (!one_tap || ts == 0)) {
+          const int kh = tap / d.KW, kw = tap - kh * d.KW;
+          const int tapoff = kh * a.HW + kw;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int ks = hf * 4 + kk;
+            if (one_tap && ks != wave) continue;   // 1-tap: the waves split the patch's pixels
+            const int p0 = pk[2 * ks] + tapoff, p1 = pk[2 * ks + 1] + tapoff;
+            const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
+            const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
+            const bf16x8 ah = tr_read8(halo_hi + o0, halo_hi + o1);
+            if (NSPLIT == 3) {
+              const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
+              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[ts], 0, 0, 0);
+              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[ts], 0, 0, 0);
+            }
+            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc[ts], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- accumulate into dW: D[row = ci][col = co]
+  const int lr = lane & 31, lh = lane >> 5;
+  const int co = co_base + lr;
+#pragma unroll
+  for (int ts = 0; ts < MAXSLOT; ++ts) {
+    const int tap = one_tap ? 0 : wave + NW * ts;
+    if (tap < a.ntaps && (!one_tap || ts == 0) && co < d.Cout) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < d.Cin) atomicAdd(a.dw + ((size_t)tap * d.Cin + ci) * a.Cout4 + co, acc[ts][r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 [Cout][Cin][taps] -> bf16 [tap][chunk][npad][hi 32 | lo 32]
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, int N, int K, int npad, int nchunk,
+                                        const float* __restrict__ src, __bf16* __restrict__ dst) {
+  const size_t total = (size_t)taps * nchunk * npad * 32;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i % 32;
+  size_t r = i / 32;
+  const int n = r % npad; r /= npad;
+  const int chunk = r % nchunk;
+  const int tap = r / nchunk;
+  const int k = chunk * 32 + j;
+  float v = 0.f;
+  if (n < N && k < K) {
+    if (mode == 0) v = src[((size_t)n * Cin + k) * taps + tap];                    // N = Cout, K = Cin
+    else v = src[((size_t)k * Cin + n) * taps + (taps - 1 - tap)];                 // N = Cin,  K = Cout
+  }
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  const size_t row = ((size_t)(tap * nchunk + chunk) * npad + n) * 64;
+  dst[row + j] = h;
+  dst[row + 32 + j] = l;
+}
+
+struct TileChoice {
+  int NI, TH, TW;
+};
+
+// Patch shape maximising the fraction of the 128 GEMM rows that are real output pixels, subject to the halo
+// fitting in LDS.  Cached per geometry.
+TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride) {
+  static std::mutex mu;
+  static std::unordered_map<unsigned long long, TileChoice> cache;
+  const unsigned long long key = ((unsigned long long)N << 44) ^ ((unsigned long long)OH << 32) ^
+                                 ((unsigned long long)OW << 20) ^ (KH << 12) ^ (KW << 4) ^ stride;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  TileChoice best{1, 1, 1};
+  double best_eff = -1.0;
+  for (int th = 1; th <= OH && th <= BM; ++th) {
+    for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
+      const int hh = (th - 1) * stride + KH, hw = (tw - 1) * stride + KW;
+      if (hh * hw > MAXPOS) continue;
+      int ni = 1;
+      if (th == OH && tw == OW) {
+        ni = BM / (th * tw);
+        if (ni > N) ni = N;
+        while (ni > 1 && ni * hh * hw > MAXPOS) --ni;
+      }
+      const long long tiles = (long long)((N + ni - 1) / ni) * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
+      double eff = (double)N * OH * OW / ((double)tiles * BM);
+      eff += 1e-4 * tw;  // tie-break: wider patches (longer contiguous runs in memory)
+      if (eff > best_eff) {
+        best_eff = eff;
+        best = TileChoice{ni, th, tw};
+      }
+    }
+  }
+  std::lock_guard<std::mutex> g(mu);
+  cache[key] = best;
+  return best;
+}
+
+template <int BN, int WM, int WN, int NSPLIT>
+int launch_halo(const HArgs& a, int gx, int gy, size_t lds, hipStream_t s) {
+  auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, a);
+  return vca_launch_status();
+}
+
+}  // namespace
+
+extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, const float* gy,
+                                   const float* in_scale, const float* in_shift, const float* in_alpha,
+                                   float* dwpack, void* stream) {
+  VCA_CHECK_ARG(d && x && gy && dwpack && (nsplit == 1 || nsplit == 3));
+  VCA_CHECK_ARG(d->N > 0 && d->D == 1 && d->OD == 1 && d->KD == 1 && d->pad_d == 0 && d->Cin > 1 && d->Cout > 0);
+  VCA_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->OH > 0 && d->OW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0);
+  VCA_CHECK_ARG(d->pad_h >= 0 && d->pad_w >= 0 && d->dil == 1 && (d->ups == 0 || d->ups == 1));
+  VCA_CHECK_ARG(d->act >= 0 && d->act <= 3 && (in_scale == nullptr) == (in_shift == nullptr));
+  VCA_CHECK_ARG(d->act != VCA_ACT_PRELU || in_alpha);
+  VCA_CHECK_ARG(d->KH * d->KW <= 32);
+  WArgs a;
+  a.d = *d;
+  a.x = x; a.gy = gy; a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.dw = dwpack;
+  a.Cout4 = (d->Cout + 3) & ~3;
+  a.ntaps = d->KH * d->KW;
+  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride);
+  a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
+  a.HH = (t.TH - 1) * d->stride + d->KH;
+  a.HW = (t.TW - 1) * d->stride + d->KW;
+  a.NPOS = a.HH * a.HW;
+  a.tiles_x = (d->OW + t.TW - 1) / t.TW;
+  a.tiles_y = (d->OH + t.TH - 1) / t.TH;
+  a.ntiles = a.tiles_x * a.tiles_y * ((d->N + t.NI - 1) / t.NI);
+  a.co_tiles = (d->Cout + 31) / 32;
+  const int ci_tiles = (d->Cin + 31) / 32;
+  const int out_tiles = a.co_tiles * ci_tiles;
+  int split = (2048 + out_tiles - 1) / out_tiles;
+  if (split > a.ntiles) split = a.ntiles;
+  if (split < 1) split = 1;
+  a.tiles_per_block = (a.ntiles + split - 1) / split;
+  split = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+  a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
+  a.vecB = (d->Cout % 4 == 0) ? 1 : 0;
+  const size_t lds = ((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1);
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    attr_done = true;
+  }
+  if (nsplit == 3) hipLaunchKernelGGL(conv_bf16_wgrad_kernel<3>, dim3(out_tiles, split), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(conv_bf16_wgrad_kernel<1>, dim3(out_tiles, split), dim3(512), lds, s, a);
+  return vca_launch_status();
+}
+
+extern "C" long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps) {
+  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+  const long long npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
+  return (long long)taps * nchunk * npad * 128;
+}
+
+extern "C" int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream) {
+  VCA_CHECK_ARG((mode == 0 || mode == 1) && Cout > 0 && Cin > 0 && taps > 0 && src && dst);
+  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+  const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
+  const size_t total = (size_t)taps * nchunk * npad * 32;
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     mode, Cout, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));
+  return vca_launch_status();
+}
+
+extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack,
+                                 const float* bias, const float* in_scale, const float* in_shift,
+                                 const float* in_alpha, const float* res, float* y, float* stats, void* stream) {
+  VCA_CHECK_ARG(d && x && wpack && y && (nsplit == 1 || nsplit == 3));
+  VCA_CHECK_ARG(d->N > 0 && d->D == 1 && d->OD == 1 && d->KD == 1 && d->pad_d == 0 && d->Cin > 1 && d->Cout > 0);
+  VCA_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->OH > 0 && d->OW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0);
+  VCA_CHECK_ARG(d->pad_h >= 0 && d->pad_w >= 0 && d->dil >= 1 && (d->ups == 0 || d->ups == 1));
+  VCA_CHECK_ARG(d->act >= 0 && d->act <= 3 && (in_scale == nullptr) == (in_shift == nullptr));
+  VCA_CHECK_ARG(d->act != VCA_ACT_PRELU || in_alpha);
+  VCA_CHECK_ARG((long long)d->N * d->OH * d->OW < (1ll << 31));
+  VCA_CHECK_ARG(d->KH * d->KW <= MAXPOS);
+  HArgs a;
+  a.d = *d;
+  a.x = x; a.w = reinterpret_cast<const unsigned char*>(wpack); a.bias = bias;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.res = res; a.y = y; a.stats = stats;
+  a.npad = (d->Cout + 31) / 32 * 32;
+  a.nchunk = (d->Cin + 31) / 32;
+  a.ntaps = d->KH * d->KW;
+  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride);
+  a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
+  a.HH = (t.TH - 1) * d->stride + d->KH;
+  a.HW = (t.TW - 1) * d->stride + d->KW;
+  a.NPOS = a.HH * a.HW;
+  a.tiles_x = (d->OW + t.TW - 1) / t.TW;
+  a.tiles_y = (d->OH + t.TH - 1) / t.TH;
+  a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
+  const int tiles_n = (d->N + t.NI - 1) / t.NI;
+  const int gx = a.tiles_x * a.tiles_y * tiles_n;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t halo = (size_t)a.NI * a.NPOS * 64 * (nsplit == 3 ? 2 : 1);
+#define LAUNCH_H(BN_, WM_, WN_)                                                                   \
+  do {                                                                                             \
+    const size_t lds = halo + 2 * (size_t)BN_ * (nsplit == 3 ? 128 : 64);                          \
+    const int gy = (d->Cout + BN_ - 1) / BN_;                                                      \
+    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3>(a, gx, gy, lds, s)                          \
+                       : launch_halo<BN_, WM_, WN_, 1>(a, gx, gy, lds, s);                         \
+  } while (0)
+  if (d->Cout > 64) LAUNCH_H(128, 2, 2);
+  else if (d->Cout > 32) LAUNCH_H(64, 2, 2);
+  else LAUNCH_H(32, 4, 1);
+#undef LAUNCH_H
+}

@@ -66,8 +66,14 @@ __global__ __launch_bounds__(THR) void l1_bwd_kernel(size_t n, const float* __re
 __global__ __launch_bounds__(THR) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   float eps, float wd, float bc1, float bc2_sqrt,
+                                                   const int* __restrict__ step_dev) {
   const size_t n4 = n >> 2;
+  if (step_dev) {   // step count lives on the device (the launch is replayed from a HIP graph)
+    const double t = (double)step_dev[0];
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < n4; i += (size_t)gridDim.x * THR) {
     float4 P = reinterpret_cast<float4*>(p)[i];
@@ -134,11 +140,13 @@ extern "C" int vca_l1_bwd_f32(long long n, const float* a, const float* b, float
 }
 
 extern "C" int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
-  VCA_CHECK_ARG(n > 0 && (n % 4) == 0 && p && g && m && v && step >= 1);
+                            float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                            void* stream) {
+  VCA_CHECK_ARG(n > 0 && (n % 4) == 0 && p && g && m && v && (step >= 1 || step_dev));
+  if (step < 1) step = 1;
   const double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
   const float bc1 = (float)bc1d;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n / 4)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, p, g, m,
-                     v, vmax, lr, beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d));
+                     v, vmax, lr, beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d), step_dev);
   return vca_launch_status();
 }

@@ -34,8 +34,23 @@ def _wdims(w):
     return cout, cin, taps
 
 
+_precision = ['fp32']
+
+
+def set_precision(mode):
+    """Arithmetic of the matrix-core convolutions: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, three bf16 MFMAs
+    per product, fp32 accumulate: ~fp32 accuracy) or 'bf16' (single bf16 product)."""
+    assert mode in ('fp32', 'bf16x3', 'bf16')
+    _precision[0] = mode
+
+
+def get_precision():
+    return _precision[0]
+
+
 def _pack(w, mode):
-    """mode 0: forward layout [taps][Cin][Cout4]; mode 1: input-gradient layout [taps][Cout][Cin4]."""
+    """mode 0: forward layout [taps][Cin][Cout4]; mode 1: input-gradient layout [taps][Cout][Cin4];
+    modes 10 / 11: the same two roles in the split-bf16 layout [tap][chunk][n][hi 32 | lo 32]."""
     cout, cin, taps = _wdims(w)
     cacheable = isinstance(w, torch.nn.Parameter)
     if cacheable:
@@ -43,9 +58,15 @@ def _pack(w, mode):
         if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == (w._version, _param_epoch[0]):
             return ent[1][mode][1]
     wd = w.detach().contiguous()
-    row = ((cout + 3) // 4 * 4) if mode == 0 else ((cin + 3) // 4 * 4)
-    out = torch.empty((taps, cin if mode == 0 else cout, row), device=w.device, dtype=torch.float32)
-    check(_lib.lib().vca_pack_weight_f32(mode, cout, cin, taps, ptr(wd), ptr(out), 0.0, stream()), 'pack_weight')
+    if mode >= 10:
+        nbytes = _lib.lib().vca_pack_weight_bf16_bytes(mode - 10, cout, cin, taps)
+        out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        check(_lib.lib().vca_pack_weight_bf16(mode - 10, cout, cin, taps, ptr(wd), out.data_ptr(), stream()),
+              'pack_weight_bf16')
+    else:
+        row = ((cout + 3) // 4 * 4) if mode == 0 else ((cin + 3) // 4 * 4)
+        out = torch.empty((taps, cin if mode == 0 else cout, row), device=w.device, dtype=torch.float32)
+        check(_lib.lib().vca_pack_weight_f32(mode, cout, cin, taps, ptr(wd), ptr(out), 0.0, stream()), 'pack_weight')
     if cacheable:
         key = id(w)
         ent = _pack_cache.get(key)
@@ -95,11 +116,20 @@ class ConvCfg:
                         self.stride, 0, 0, 0.0, 1.0)
 
 
+def _nsplit():
+    return {'fp32': 0, 'bf16x3': 3, 'bf16': 1}[_precision[0]]
+
+
 def _conv_fwd_raw(x, w, bias, cfg):
     y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
     d = cfg.desc()
-    check(_lib.lib().vca_conv_fwd_f32(d, ptr(x), ptr(_pack(w, 0)), ptr(bias), None, None, None, None, ptr(y), None,
-                                      stream()), 'conv_fwd')
+    ns = _nsplit()
+    if ns and cfg.cin > 1 and cfg.kd == 1:
+        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
+                                           ptr(y), None, stream()), 'conv_fwd_bf16')
+    else:
+        check(_lib.lib().vca_conv_fwd_f32(d, ptr(x), ptr(_pack(w, 0)), ptr(bias), None, None, None, None, ptr(y),
+                                          None, stream()), 'conv_fwd')
     return y
 
 
@@ -107,8 +137,13 @@ def _conv_dgrad_raw(gy, w, cfg):
     he, we = cfg.hin << cfg.ups, cfg.win << cfg.ups
     gx = torch.empty((cfg.n, he, we, cfg.cin), device=gy.device, dtype=torch.float32)
     d = cfg.dgrad_desc()
-    check(_lib.lib().vca_conv_fwd_f32(d, ptr(gy), ptr(_pack(w, 1)), None, None, None, None, None, ptr(gx), None,
-                                      stream()), 'conv_dgrad')
+    ns = _nsplit()
+    if ns and cfg.cout > 1:
+        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, None,
+                                           ptr(gx), None, stream()), 'conv_dgrad_bf16')
+    else:
+        check(_lib.lib().vca_conv_fwd_f32(d, ptr(gy), ptr(_pack(w, 1)), None, None, None, None, None, ptr(gx), None,
+                                          stream()), 'conv_dgrad')
     if cfg.ups:
         gx = gx.view(cfg.n, cfg.hin, 2, cfg.win, 2, cfg.cin).sum((2, 4))
     return gx.view(cfg.xshape)
@@ -117,8 +152,13 @@ def _conv_dgrad_raw(gy, w, cfg):
 def _conv_wgrad_raw(x, gy, cfg):
     cout, cin, taps = cfg.cout, cfg.cin, cfg.kd * cfg.kh * cfg.kw
     dwp = torch.zeros((taps, cin, (cout + 3) // 4 * 4), device=x.device, dtype=torch.float32)
-    check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
-          'conv_wgrad')
+    ns = _nsplit()
+    if ns and cin > 1 and cfg.kd == 1 and taps <= 32:
+        check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
+              'conv_wgrad_bf16')
+    else:
+        check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
+              'conv_wgrad')
     gw = torch.empty(cfg.pshape, device=x.device, dtype=torch.float32)
     check(_lib.lib().vca_pack_weight_f32(2, cout, cin, taps, ptr(dwp), ptr(gw), 0.0, stream()), 'unpack_wgrad')
     return gw
@@ -550,7 +590,8 @@ def masked_attention(q, k, v, lens, scale):
     """softmax(q k^T * scale, keys >= lens[b] masked) v   (generator.py:161-167)."""
     att = torch.bmm(q, k.transpose(1, 2)) * scale
     S = att.shape[2]
-    lens_t = torch.as_tensor([int(l) for l in lens], device=att.device)
+    lens_t = lens if (torch.is_tensor(lens) and lens.device == att.device) else \
+        torch.as_tensor([int(l) for l in lens], device=att.device)
     pad = torch.arange(S, device=att.device)[None, None, :] >= lens_t[:, None, None]
     att = att.masked_fill(pad, float('-inf')).softmax(2)
     return torch.bmm(att, v)
@@ -599,6 +640,7 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
         self.param_groups = [dict(lr=lr)]       # the reference reads param_groups[0]['lr'] for logging
         self.t = 0
+        self.t_dev = torch.zeros(1, device=groups[0][0].device, dtype=torch.int32)   # graph-replayable step count
         self.state = [dict(m=torch.zeros_like(f), v=torch.zeros_like(f),
                            vmax=torch.zeros_like(f) if amsgrad else None) for f, _ in groups]
 
@@ -608,9 +650,10 @@ class FusedAdam:
 
     def step(self):
         self.t += 1
+        self.t_dev += 1
         lr = self.param_groups[0]['lr']
         for (f, g), st in zip(self.groups, self.state):
             check(_lib.lib().vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
-                                          stream()), 'adam')
+                                          self.t_dev.data_ptr(), stream()), 'adam')
         _param_epoch[0] += 1

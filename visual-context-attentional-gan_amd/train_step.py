@@ -138,3 +138,40 @@ class GanStep:
                     g_sync_loss=g_sync.detach(), recon_loss=recon.detach(), g_loss=g_loss.detach(),
                     grad_p=torch.stack([x.detach() for x in grad_p]),
                     g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+
+
+class GraphedStep:
+    """A GanStep captured once into a HIP graph and replayed: one graph launch per training step instead of several
+    thousand kernel launches issued from Python.  Inputs are copied into static device buffers before each replay;
+    the returned tensors are the graph's static outputs (overwritten by the next call).  Shapes are fixed at capture."""
+
+    def __init__(self, step, mel, spec, vid, vid_len, noise, warmup=2):
+        self.step = step
+        dev = mel.device
+        self.static = dict(mel=mel.clone(), spec=spec.clone(), vid=vid.clone(), noise=noise.clone(),
+                           vid_len=torch.as_tensor([int(l) for l in vid_len], device=dev))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # allocator, lazy module state and kernel attributes settle here
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        self.warmup_steps = warmup
+
+    def _run(self):
+        s = self.static
+        return self.step(s['mel'], s['spec'], s['vid'], s['vid_len'], noise=s['noise'])
+
+    def __call__(self, mel, spec, vid, vid_len=None, noise=None):
+        s = self.static
+        for k, v in (('mel', mel), ('spec', spec), ('vid', vid), ('noise', noise)):
+            if v is not None and v.data_ptr() != s[k].data_ptr():
+                s[k].copy_(v, non_blocking=True)
+        if vid_len is not None and not (torch.is_tensor(vid_len) and vid_len.data_ptr() == s['vid_len'].data_ptr()):
+            s['vid_len'].copy_(torch.as_tensor([int(l) for l in vid_len]), non_blocking=True)
+        self.graph.replay()
+        return self.out
