@@ -37,9 +37,24 @@ struct HArgs {
   float* stats;
   int npad, nchunk, ntaps;
   int NI, TH, TW, HH, HW, NPOS;
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, nsub;
   int vecA;
+  int ksplit;  // >1: blockIdx.z owns a range of channel slices and adds its partial sums atomically
 };
+
+// A workgroup's GEMM rows are NI "slots" of TH x TW output pixels.  Slots are consecutive entries of the list of all
+// (image, row band, column band) sub-patches, so one workgroup can hold several images of a small map or several
+// bands of one image; every slot has its own halo region in LDS.
+__device__ __forceinline__ bool slot_origin(int sid, int nsub, int tiles_x, int tiles_y, int TH, int TW, int& n,
+                                            int& oy0, int& ox0) {
+  const int per_img = tiles_x * tiles_y;
+  n = sid / per_img;
+  const int r = sid - n * per_img;
+  const int tiy = r / tiles_x;
+  oy0 = tiy * TH;
+  ox0 = (r - tiy * tiles_x) * TW;
+  return sid < nsub;
+}
 
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   bf16x8 h, l;
@@ -69,11 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   unsigned char* halo_lo = smem + npos_total * 64;
   unsigned char* bbase = smem + npos_total * 64 * (NSPLIT == 3 ? 2 : 1);
 
-  int bx = blockIdx.x;
-  const int tix = bx % a.tiles_x; bx /= a.tiles_x;
-  const int tiy = bx % a.tiles_y;
-  const int tin = bx / a.tiles_y;
-  const int nb = tin * a.NI, oy0 = tiy * a.TH, ox0 = tix * a.TW;
+  const int sid0 = blockIdx.x * a.NI;   // first sub-patch of this workgroup
   const int n0 = blockIdx.y * BN;
   const int He = d.Hin << d.ups, We = d.Win << d.ups;
   const int tpix = a.TH * a.TW;
@@ -122,16 +133,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     }
   };
 
-  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+  const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
+  const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
+  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
     __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
     // ---- stage the halo of this 32-channel slice
     for (int it = tid; it < npos_total * 2; it += 256) {
       const int pos = it >> 1, half = it & 1;
       const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
       const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      int n, oy0, ox0;
+      bool ok = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
       int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
-      const int n = nb + img;
-      bool ok = n < d.N && vy >= 0 && vx >= 0;
+      ok = ok && vy >= 0 && vx >= 0;
       if (d.dil > 1) {
         ok = ok && (vy % d.dil == 0) && (vx % d.dil == 0);
         vy /= d.dil;
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * WTN + j * 32 + lr;
     const bool nv = n < d.Cout;
-    const float b = (nv && a.bias) ? a.bias[n] : 0.f;
+    const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -241,15 +255,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
         const int m = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int img = m / tpix, rem = m - img * tpix;
         const int ty = rem / a.TW, tx = rem - ty * a.TW;
-        const int nn = nb + img, oy = oy0 + ty, ox = ox0 + tx;
-        if (nv && img < a.NI && nn < d.N && oy < d.OH && ox < d.OW) {
+        int nn, oy0, ox0;
+        const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, nn, oy0, ox0);
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (nv && img < a.NI && sv && oy < d.OH && ox < d.OW) {
           float v = acc[i][j][r];
           s1 += v;
           s2 += v * v;
           v += b;
           const size_t o = ((size_t)(nn * d.OH + oy) * d.OW + ox) * d.Cout + n;
-          if (a.res) v += a.res[o];
-          a.y[o] = v * d.out_scale;
+          if (a.ksplit > 1) {
+            atomicAdd(a.y + o, v);
+          } else {
+            if (a.res) v += a.res[o];
+            a.y[o] = v * d.out_scale;
+          }
         }
       }
     }
@@ -272,9 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 // the input halo [position][32 ci] and the output-gradient tile [pixel][32 co] in LDS as hi/lo bf16, and the MFMA
 // operands (which need 8 consecutive reduction indices per lane) are fetched with the transposing LDS read
 // ds_read_b64_tr_b16: 4 rows (pixels) x 16 columns (channels) per 16-lane group, delivered column-major.  The
-// taps are dealt round-robin to the 8 waves (each keeps its taps' accumulators in registers for the whole walk);
-// a 1-tap convolution instead splits the patch's pixels across the waves.  Partial tiles are added to dW with
-// fp32 atomics (pixels are also split across workgroups).
+// ntaps*8 (tap, 16-pixel slice) units of a patch are dealt to the 8 waves in equal contiguous runs, so every wave
+// issues the same number of MFMAs whatever the filter size, and keeps the accumulators of the (at most 5) taps its
+// run touches in registers for the whole walk.  Partial tiles are added to dW with fp32 atomics (pixels are also
+// split across workgroups).
 // ------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -288,7 +309,7 @@ struct WArgs {
   float* dw;  // fp32 [tap][Cin][Cout4]
   int Cout4, ntaps;
   int NI, TH, TW, HH, HW, NPOS;
-  int tiles_x, tiles_y, ntiles, tiles_per_block, co_tiles;
+  int tiles_x, tiles_y, nsub, ntiles, tiles_per_block, co_tiles;
   int vecA, vecB;
 };
 
@@ -303,11 +324,12 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool RR>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int MAXSLOT = 4;  // taps per wave (25 taps / 8 waves)
-  constexpr int NW = 8;
+  constexpr int MAXSLOT = 5;  // distinct taps a wave's run of units can touch (<= 32 taps)
+  constexpr int RRSLOT = 4;   // taps per wave when whole taps are dealt round-robin (17..32 taps)
+  const bool one_tap = false;
   const vca_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npos_total = a.NI * a.NPOS;
@@ -320,7 +342,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   const int ci_base = cit * 32, co_base = cot * 32;
   const int He = d.Hin << d.ups, We = d.Win << d.ups;
   const int tpix = a.TH * a.TW;
-  const bool one_tap = a.ntaps == 1;
+  // this wave's run of (tap, slice) units: u = tap*8 + slice
+  const int u_first = wave * a.ntaps, u_last = u_first + a.ntaps - 1;
+  const int tap_first = u_first >> 3, tap_last = u_last >> 3;
 
   // transposed-read geometry of this lane: column (channel) group and reduction-row offsets
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
@@ -345,20 +369,17 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   const int pt_beg = blockIdx.y * a.tiles_per_block;
   const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
   for (int pt = pt_beg; pt < pt_end; ++pt) {
-    int bx = pt;
-    const int tix = bx % a.tiles_x; bx /= a.tiles_x;
-    const int tiy = bx % a.tiles_y;
-    const int tin = bx / a.tiles_y;
-    const int nb = tin * a.NI, oy0 = tiy * a.TH, ox0 = tix * a.TW;
+    const int sid0 = pt * a.NI;
     __syncthreads();
     // ---- input halo of this patch, channels ci_base .. ci_base+31
     for (int it = tid; it < npos_total * 2; it += 512) {
       const int pos = it >> 1, half = it & 1;
       const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
       const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      int n, oy0, ox0;
+      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
       int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
-      const int n = nb + img;
-      const bool ok = n < d.N && vy >= 0 && vx >= 0 && vy < He && vx < We;
+      const bool ok = sv && vy >= 0 && vx >= 0 && vy < He && vx < We;
       vy >>= d.ups;
       vx >>= d.ups;
       const int ci0 = ci_base + half * 16;
@@ -407,12 +428,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
       const int m = tid >> 2, qt = tid & 3;
       const int img = m / tpix, rem = m - img * tpix;
       const int ty = rem / a.TW, tx = rem - ty * a.TW;
-      const int n = nb + img, oy = oy0 + ty, ox = ox0 + tx;
+      int n, oy0, ox0;
+      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      const int oy = oy0 + ty, ox = ox0 + tx;
       const int c0 = co_base + qt * 8;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (img < a.NI && n < d.N && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+      if (img < a.NI && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
         const float* src = a.gy + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.Cout + c0;
         if (a.vecB && c0 + 8 <= d.Cout) {
           const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
@@ -431,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
     }
     __syncthreads();
 
+    if constexpr (RR) {
     // ---- two halves of the patch (64 pixels each): the B fragments (output gradient) of a half stay in
     //      registers while every tap of this wave sweeps it
 #pragma unroll
@@ -445,8 +469,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
         if (NSPLIT == 3) bl[kk] = tr_read8(gy_lo + o0, gy_lo + o1);
       }
 #pragma unroll
-      for (int ts = 0; ts < MAXSLOT; ++ts) {
-        const int tap = one_tap ? 0 : wave + NW * ts;
+      for (int ts = 0; ts < RRSLOT; ++ts) {
+        const int tap = one_tap ? 0 : wave + 8 * ts;
         if (tap < a.ntaps && (!one_tap || ts == 0)) {
           const int kh = tap / d.KW, kw = tap - kh * d.KW;
           const int tapoff = kh * a.HW + kw;
@@ -468,14 +492,46 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
         }
       }
     }
+    } else {
+    // ---- MFMA work units (tap, 16-pixel slice): ntaps*8 of them, dealt in contiguous runs of ntaps per wave
+#pragma unroll
+    for (int sl = 0; sl < MAXSLOT; ++sl) {
+      const int tap = tap_first + sl;
+      if (tap <= tap_last) {
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        const int tapoff = kh * a.HW + kw;
+        const int ks_lo = max(u_first - tap * 8, 0), ks_hi = min(u_last - tap * 8, 7);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks < ks_lo || ks > ks_hi) continue;
+          const int k0 = ks * 16 + kq, k1 = k0 + 4;
+          const int g0 = k0 * 64 + ((colchunk ^ ((k0 >> 2) & 3)) << 4) + colbyte;
+          const int g1 = k1 * 64 + ((colchunk ^ ((k1 >> 2) & 3)) << 4) + colbyte;
+          const int p0 = pk[2 * ks] + tapoff, p1 = pk[2 * ks + 1] + tapoff;
+          const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
+          const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
+          const bf16x8 bh = tr_read8(gy_hi + g0, gy_hi + g1);
+          const bf16x8 ah = tr_read8(halo_hi + o0, halo_hi + o1);
+          if (NSPLIT == 3) {
+            const bf16x8 bl = tr_read8(gy_lo + g0, gy_lo + g1);
+            const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
+            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sl], 0, 0, 0);
+            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sl], 0, 0, 0);
+          }
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sl], 0, 0, 0);
+        }
+      }
+    }
+    }
   }
 
+  if constexpr (RR) {
   // ---- accumulate into dW: D[row = ci][col = co]
   const int lr = lane & 31, lh = lane >> 5;
   const int co = co_base + lr;
 #pragma unroll
-  for (int ts = 0; ts < MAXSLOT; ++ts) {
-    const int tap = one_tap ? 0 : wave + NW * ts;
+  for (int ts = 0; ts < RRSLOT; ++ts) {
+    const int tap = one_tap ? 0 : wave + 8 * ts;
     if (tap < a.ntaps && (!one_tap || ts == 0) && co < d.Cout) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -483,6 +539,22 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
         if (ci < d.Cin) atomicAdd(a.dw + ((size_t)tap * d.Cin + ci) * a.Cout4 + co, acc[ts][r]);
       }
     }
+  }
+  } else {
+  // ---- accumulate into dW: D[row = ci][col = co]
+  const int lr = lane & 31, lh = lane >> 5;
+  const int co = co_base + lr;
+#pragma unroll
+  for (int sl = 0; sl < MAXSLOT; ++sl) {
+    const int tap = tap_first + sl;
+    if (tap <= tap_last && co < d.Cout) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < d.Cin) atomicAdd(a.dw + ((size_t)tap * d.Cin + ci) * a.Cout4 + co, acc[sl][r]);
+      }
+    }
+  }
   }
 }
 
@@ -518,33 +590,35 @@ struct TileChoice {
 
 // Patch shape maximising the fraction of the 128 GEMM rows that are real output pixels, subject to the halo
 // fitting in LDS.  Cached per geometry.
-TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride) {
+TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Cout) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, TileChoice> cache;
   const unsigned long long key = ((unsigned long long)N << 44) ^ ((unsigned long long)OH << 32) ^
-                                 ((unsigned long long)OW << 20) ^ (KH << 12) ^ (KW << 4) ^ stride;
+                                 ((unsigned long long)OW << 20) ^ (KH << 12) ^ (KW << 4) ^ stride ^
+                                 ((unsigned long long)(Cout > 96 ? 3 : (Cout > 32 ? 2 : 1)) << 58);
   {
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
   }
+  // cost model per workgroup and 32-channel slice: MFMA cycles of all taps + cycles to stage the halo positions
   TileChoice best{1, 1, 1};
-  double best_eff = -1.0;
+  double best_cost = 1e300;
+  const int bn32 = Cout > 96 ? 4 : (Cout > 32 ? 2 : 1);
+  const double mfma = (double)KH * KW * 192.0 * bn32;
   for (int th = 1; th <= OH && th <= BM; ++th) {
     for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
       const int hh = (th - 1) * stride + KH, hw = (tw - 1) * stride + KW;
       if (hh * hw > MAXPOS) continue;
-      int ni = 1;
-      if (th == OH && tw == OW) {
-        ni = BM / (th * tw);
-        if (ni > N) ni = N;
-        while (ni > 1 && ni * hh * hw > MAXPOS) --ni;
-      }
-      const long long tiles = (long long)((N + ni - 1) / ni) * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
-      double eff = (double)N * OH * OW / ((double)tiles * BM);
-      eff += 1e-4 * tw;  // tie-break: wider patches (longer contiguous runs in memory)
-      if (eff > best_eff) {
-        best_eff = eff;
+      const long long nsub = (long long)N * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
+      int ni = BM / (th * tw);
+      if (ni > nsub) ni = (int)nsub;
+      while (ni > 1 && ni * hh * hw > MAXPOS) --ni;
+      const long long groups = (nsub + ni - 1) / ni;
+      double cost = (double)groups * (mfma + 6.0 * ni * hh * hw);
+      cost *= 1.0 + 0.02 / tw;   // tie-break: wider patches (longer contiguous runs, fewer LDS bank conflicts)
+      if (cost < best_cost) {
+        best_cost = cost;
         best = TileChoice{ni, th, tw};
       }
     }
@@ -555,7 +629,7 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride) {
 }
 
 template <int BN, int WM, int WN, int NSPLIT>
-int launch_halo(const HArgs& a, int gx, int gy, size_t lds, hipStream_t s) {
+int launch_halo(HArgs a, int gx, int gy, size_t lds, hipStream_t s) {
   auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -564,7 +638,21 @@ int launch_halo(const HArgs& a, int gx, int gy, size_t lds, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, a);
+  // few output tiles but a deep reduction (the discriminators' 5x5 heads on 5x18 maps): split the channel slices
+  // over blockIdx.z so the launch covers the chip; partial sums meet in y through fp32 atomics
+  a.ksplit = 1;
+  const long long blocks = (long long)gx * gy;
+  if (blocks < 224 && a.nchunk >= 4 && !a.res && !a.stats && a.d.out_scale == 1.0f) {
+    int ks = (int)((448 + blocks - 1) / blocks);
+    if (ks > a.nchunk / 2) ks = a.nchunk / 2;
+    if (ks > 1) {
+      a.ksplit = ks;
+      const size_t bytes = (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout * sizeof(float);
+      hipError_t e = hipMemsetAsync(a.y, 0, bytes, s);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, gy, a.ksplit), dim3(256), lds, s, a);
   return vca_launch_status();
 }
 
@@ -585,18 +673,20 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.x = x; a.gy = gy; a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.dw = dwpack;
   a.Cout4 = (d->Cout + 3) & ~3;
   a.ntaps = d->KH * d->KW;
-  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride);
+  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
   a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
   a.HH = (t.TH - 1) * d->stride + d->KH;
   a.HW = (t.TW - 1) * d->stride + d->KW;
   a.NPOS = a.HH * a.HW;
   a.tiles_x = (d->OW + t.TW - 1) / t.TW;
   a.tiles_y = (d->OH + t.TH - 1) / t.TH;
-  a.ntiles = a.tiles_x * a.tiles_y * ((d->N + t.NI - 1) / t.NI);
+  a.nsub = d->N * a.tiles_x * a.tiles_y;
+  a.ntiles = (a.nsub + t.NI - 1) / t.NI;
   a.co_tiles = (d->Cout + 31) / 32;
   const int ci_tiles = (d->Cin + 31) / 32;
   const int out_tiles = a.co_tiles * ci_tiles;
   int split = (2048 + out_tiles - 1) / out_tiles;
+  if (split > 256) split = 256;          // bounds the atomic adds that land on one dW tile
   if (split > a.ntiles) split = a.ntiles;
   if (split < 1) split = 1;
   a.tiles_per_block = (a.ntiles + split - 1) / split;
@@ -607,16 +697,26 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
+    const void* ks[4] = {reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, false>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, true>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>)};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_done = true;
   }
-  if (nsplit == 3) hipLaunchKernelGGL(conv_bf16_wgrad_kernel<3>, dim3(out_tiles, split), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL(conv_bf16_wgrad_kernel<1>, dim3(out_tiles, split), dim3(512), lds, s, a);
+  // many taps: whole taps per wave (output-gradient fragments stay in registers); few taps: balanced unit runs
+  const bool rr = a.ntaps > 16;
+  const dim3 grid(out_tiles, split), blk(512);
+  if (nsplit == 3) {
+    if (rr) hipLaunchKernelGGL((conv_bf16_wgrad_kernel<3, true>), grid, blk, lds, s, a);
+    else hipLaunchKernelGGL((conv_bf16_wgrad_kernel<3, false>), grid, blk, lds, s, a);
+  } else {
+    if (rr) hipLaunchKernelGGL((conv_bf16_wgrad_kernel<1, true>), grid, blk, lds, s, a);
+    else hipLaunchKernelGGL((conv_bf16_wgrad_kernel<1, false>), grid, blk, lds, s, a);
+  }
   return vca_launch_status();
 }
 
@@ -654,7 +754,7 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   a.npad = (d->Cout + 31) / 32 * 32;
   a.nchunk = (d->Cin + 31) / 32;
   a.ntaps = d->KH * d->KW;
-  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride);
+  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
   a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
   a.HH = (t.TH - 1) * d->stride + d->KH;
   a.HW = (t.TW - 1) * d->stride + d->KW;
@@ -662,8 +762,8 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   a.tiles_x = (d->OW + t.TW - 1) / t.TW;
   a.tiles_y = (d->OH + t.TH - 1) / t.TH;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
-  const int tiles_n = (d->N + t.NI - 1) / t.NI;
-  const int gx = a.tiles_x * a.tiles_y * tiles_n;
+  a.nsub = d->N * a.tiles_x * a.tiles_y;
+  const int gx = (a.nsub + t.NI - 1) / t.NI;
   hipStream_t s = (hipStream_t)stream;
   const size_t halo = (size_t)a.NI * a.NPOS * 64 * (nsplit == 3 ? 2 : 1);
 #define LAUNCH_H(BN_, WM_, WN_)                                                                   \
