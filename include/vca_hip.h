@@ -137,6 +137,35 @@ int vca_maxpool3s2_bwd_f32(int N, int H, int W, int C, const float* gy, const un
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Visual Context Attention core (AVAttention.forward, generator.py:161-167): per sample
+ *   ctx = softmax(q k^T * scale with keys >= lens[b] masked to -inf) v
+ * q, ctx: (B, Tq, D); k, v: (B, S, D); D = 256, S <= 160; lens: B int32 on the device.  probs (B, Tq, S) receives
+ * the attention weights for the backward call, which returns dq and the (internally zeroed, atomically
+ * accumulated) dk, dv.  The q/k/v/output projections (generator.py:158-159,166,168) run on the convolution
+ * kernels as 1x1 convolutions.
+ * ---------------------------------------------------------------------------------------------- */
+int vca_attention_fwd_f32(int B, int Tq, int S, int D, const float* q, const float* k, const float* v,
+                          const int* lens, float scale, float* ctx, float* probs, void* stream);
+int vca_attention_bwd_f32(int B, int Tq, int S, int D, const float* dctx, const float* q, const float* k,
+                          const float* v, const float* probs, float scale, float* dq, float* dk, float* dv,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRU cell (nn.GRU(512,512,2,bidirectional) of visual_front.py:20,33-34).  The input and recurrent gate products
+ * x W_ih^T + b_ih and h W_hh^T + b_hh run on the convolution kernels as 1x1 "convolutions"; these two kernels are
+ * the pointwise gate arithmetic of one time step and its backward.  gi/gh: (B, 3H) rows [reset | update | new].
+ *   forward:  h_new (B,H) contiguous, and the same values to out[b*out_stride + j] (the time step's slot of the
+ *             layer output); save (B,4H) keeps r, z, n and the recurrent new-gate pre-activation for backward.
+ *   backward: dh = dout[b*dout_stride + j] + dh_a + dh_b (either may be NULL) -> d_gi, d_gh (B,3H) and
+ *             dh_direct = dh*z, the part of d h_prev that does not pass through W_hh.
+ * ---------------------------------------------------------------------------------------------- */
+int vca_gru_cell_fwd_f32(int B, int H, const float* gi, const float* gh, const float* h_prev, float* h_new,
+                         float* out, int out_stride, float* save, void* stream);
+int vca_gru_cell_bwd_f32(int B, int H, const float* dout, int dout_stride, const float* dh_a, const float* dh_b,
+                         const float* save, const float* h_prev, float* d_gi, float* d_gh, float* dh_direct,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Losses and optimiser.
  * ---------------------------------------------------------------------------------------------- */
 /* out[0] += scale * sum softplus(sign*x)  and its backward (gan_loss, generator.py:363-366). */

@@ -162,3 +162,51 @@ def test_losses_and_adam():
             opt_d.zero_grad(); lin_d(xin.cuda()).square().sum().backward(); opt_d.step()
         for pr, pd in zip(lin_r.parameters(), lin_d.parameters()):
             assert rel_err(pd, pr) < 1e-5
+
+
+@gpu
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-5), ('bf16x3', 2e-4)])
+def test_gru_matches_torch(prec, tol):
+    from vcagan_amd import ops
+    ops.set_precision(prec)
+    try:
+        torch.manual_seed(3)
+        ref = nn.GRU(48, 32, 2, bidirectional=True)
+        mod = nn.GRU(48, 32, 2, bidirectional=True)
+        mod.load_state_dict(ref.state_dict())
+        mod.cuda()
+        x = torch.randn(5, 9, 48)             # (B, T, I)
+        xr = x.clone().requires_grad_(True)
+        yr, _ = ref(xr.transpose(0, 1))
+        yr = yr.transpose(0, 1)
+        gy = torch.randn(yr.shape)
+        yr.backward(gy)
+        xd = x.cuda().requires_grad_(True)
+        y = ops.gru(xd, mod, False)
+        y.backward(gy.cuda())
+        assert rel_err(y, yr) < tol
+        assert rel_err(xd.grad, xr.grad) < tol
+        for (n, pr), (_, pd) in zip(ref.named_parameters(), mod.named_parameters()):
+            assert rel_err(pd.grad, pr.grad) < tol * 2, n
+    finally:
+        ops.set_precision('fp32')
+
+
+@gpu
+@pytest.mark.parametrize('B,Tq,S,lens', [(2, 20, 20, [20, 13]), (3, 150, 75, [75, 40, 1]), (2, 300, 150, [150, 77])])
+def test_attention_core(B, Tq, S, lens):
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B, n, 256, generator=g) for n in (Tq, S, S))
+    gy = torch.randn(B, Tq, 256, generator=g)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    att = torch.bmm(qr, kr.transpose(1, 2)) / 16.0
+    for i, l in enumerate(lens):
+        att[i, :, l:] = float('-inf')
+    out_r = torch.bmm(att.softmax(2), vr)
+    out_r.backward(gy)
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ops.masked_attention(qd, kd, vd, ops.as_lens(lens, qd.device), 1.0 / 16.0)
+    out.backward(gy.cuda())
+    assert rel_err(out, out_r) < 1e-5
+    assert rel_err(qd.grad, qr.grad) < 2e-5 and rel_err(kd.grad, kr.grad) < 2e-5 and rel_err(vd.grad, vr.grad) < 2e-5

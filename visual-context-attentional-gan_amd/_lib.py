@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
-SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip')
+SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip')
 
 
 def build(force=False, verbose=False):
@@ -57,6 +57,10 @@ _SIGS = {
     'vca_pool2_f32': ([_I] * 7 + [_P, _P, _P], _I),
     'vca_maxpool3s2_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P], _I),
     'vca_maxpool3s2_bwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P], _I),
+    'vca_attention_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P], _I),
+    'vca_attention_bwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P], _I),
+    'vca_gru_cell_fwd_f32': ([_I, _I, _P, _P, _P, _P, _P, _I, _P, _P], _I),
+    'vca_gru_cell_bwd_f32': ([_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_softplus_sum_f32': ([_I, _P, _F, _F, _P, _P], _I),
     'vca_softplus_bwd_f32': ([_I, _P, _F, _F, _P, _P, _P], _I),
     'vca_l1_sum_f32': ([_LL, _P, _P, _F, _P, _P], _I),

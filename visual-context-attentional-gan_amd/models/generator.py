@@ -119,7 +119,7 @@ class AVAttention(nn.Module):
         q = ops.linear(qin, self.q.weight, self.q.bias)
         k = ops.linear(ph, self.k.weight, self.k.bias)
         v = ops.linear(ph, self.v.weight, self.v.bias)
-        ctx = ops.masked_attention(q, k, v, len, 1.0 / math.sqrt(self.out_dim))
+        ctx = ops.masked_attention(q, k, v, ops.as_lens(len, q.device), 1.0 / math.sqrt(self.out_dim))
         out = ops.linear(ctx, self.mel.weight, self.mel.bias)
         return out.view(B, T, Fq, -1).transpose(1, 2)
 
@@ -177,6 +177,7 @@ class Decoder(nn.Module):
         noise: optional (B, 128, 20, T) tensor; by default drawn from the CPU generator like generator.py:248."""
         B, T = x.size(0), x.size(1)
         ctx = s.transpose(1, 2).contiguous()                             # (B, T, 512)
+        len = ops.as_lens(len, x.device)
         if noise is None:
             noise = torch.randn([B, 128, 20, T])
         noise = noise.to(x.device).permute(0, 2, 3, 1)

@@ -580,21 +580,149 @@ def l1_mean(a, b, mul=1.0):
 # --------------------------------------------------------------------------- #
 # recurrent / attention / sync loss (torch operators; HIP kernels replace them one by one)
 # --------------------------------------------------------------------------- #
+def _lin_cfg(w, rows):
+    return ConvCfg((w.shape[0], w.shape[1], 1, 1), (rows, 1, 1, w.shape[1]), 1, (0, 0), 0, pshape=w.shape)
+
+
+def _gemm_nt(x2d, w, bias):
+    """x (P,I) @ w(O,I)^T + bias -> (P,O)"""
+    return _conv_fwd_raw(x2d, w, bias, _lin_cfg(w, x2d.shape[0])).view(x2d.shape[0], w.shape[0])
+
+
+def _gemm_nn(gy2d, w):
+    """gy (P,O) @ w(O,I) -> (P,I)"""
+    return _conv_dgrad_raw(gy2d, w, _lin_cfg(w, gy2d.shape[0])).view(gy2d.shape[0], w.shape[1])
+
+
+def _gemm_tn(x2d, gy2d, w):
+    """gy (P,O)^T @ x (P,I) -> (O,I), the gradient of w"""
+    return _conv_wgrad_raw(x2d, gy2d, _lin_cfg(w, x2d.shape[0]))
+
+
+class GruLayerFn(torch.autograd.Function):
+    """One bidirectional GRU layer over a time-major sequence: x (T,B,I) -> (T,B,2H).  The gate GEMMs run on the
+    matrix-core kernels, the gate arithmetic in vca_gru_cell_*; backward is explicit back-propagation through time."""
+
+    @staticmethod
+    def forward(ctx, x, *wts):
+        x = _c(x)
+        T, B, I = x.shape
+        H = wts[1].shape[1]
+        L = _lib.lib()
+        out = torch.empty((T, B, 2 * H), device=x.device, dtype=torch.float32)
+        x2 = x.view(T * B, I)
+        saved = []
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = wts[4 * d:4 * d + 4]
+            gi = _gemm_nt(x2, w_ih, b_ih).view(T, B, 3 * H)
+            hbuf = torch.empty((T, B, H), device=x.device, dtype=torch.float32)
+            save = torch.empty((T, B, 4 * H), device=x.device, dtype=torch.float32)
+            h0 = torch.zeros((B, H), device=x.device, dtype=torch.float32)
+            order = range(T) if d == 0 else range(T - 1, -1, -1)
+            prev = None
+            for t in order:
+                hp = h0 if prev is None else hbuf[prev]
+                gh = _gemm_nt(hp, w_hh, b_hh)
+                check(L.vca_gru_cell_fwd_f32(B, H, ptr(gi[t]), ptr(gh), ptr(hp), ptr(hbuf[t]),
+                                             out[t].data_ptr() + 4 * d * H, 2 * H, ptr(save[t]), stream()),
+                      'gru_cell_fwd')
+                prev = t
+            saved += [hbuf, save]
+        ctx.save_for_backward(x, *wts, *saved)
+        return out
+
+    @staticmethod
+    @once
+    def backward(ctx, dout):
+        x = ctx.saved_tensors[0]
+        wts = ctx.saved_tensors[1:9]
+        saved = ctx.saved_tensors[9:]
+        dout = _c(dout)
+        T, B, I = x.shape
+        H = wts[1].shape[1]
+        L = _lib.lib()
+        x2 = x.view(T * B, I)
+        dx = None
+        grads = []
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = wts[4 * d:4 * d + 4]
+            hbuf, save = saved[2 * d], saved[2 * d + 1]
+            d_gi = torch.empty((T, B, 3 * H), device=x.device, dtype=torch.float32)
+            d_gh = torch.empty((T, B, 3 * H), device=x.device, dtype=torch.float32)
+            zeros = torch.zeros((1, B, H), device=x.device, dtype=torch.float32)
+            # h_{prev}(t): the state the step at time t started from
+            hprev_all = torch.cat([zeros, hbuf[:-1]], 0) if d == 0 else torch.cat([hbuf[1:], zeros], 0)
+            order = range(T - 1, -1, -1) if d == 0 else range(T)
+            dh_gemm, dh_dir = None, None
+            for t in order:
+                nd = torch.empty((B, H), device=x.device, dtype=torch.float32)
+                check(L.vca_gru_cell_bwd_f32(B, H, dout[t].data_ptr() + 4 * d * H, 2 * H, ptr(dh_gemm), ptr(dh_dir),
+                                             ptr(save[t]), ptr(hprev_all[t]), ptr(d_gi[t]), ptr(d_gh[t]), ptr(nd),
+                                             stream()), 'gru_cell_bwd')
+                dh_dir = nd
+                dh_gemm = _gemm_nn(d_gh[t], w_hh)
+            gi2, gh2 = d_gi.view(T * B, 3 * H), d_gh.view(T * B, 3 * H)
+            g_w_ih = _gemm_tn(x2, gi2, w_ih)
+            g_w_hh = _gemm_tn(hprev_all.view(T * B, H), gh2, w_hh)
+            grads += [g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0)]
+            if ctx.needs_input_grad[0]:
+                part = _gemm_nn(gi2, w_ih)
+                dx = part if dx is None else dx + part
+        return (dx.view(T, B, I) if dx is not None else None,) + tuple(grads)
+
+
 def gru(x, mod, training):
-    """x: (B, T, 512) -> (B, T, 1024); 2-layer bidirectional GRU (visual_front.py:20,33-34)."""
-    out, _ = mod(x.transpose(0, 1).contiguous())
-    return out.transpose(0, 1)
+    """x: (B, T, 512) -> (B, T, 1024); 2-layer bidirectional GRU (visual_front.py:20,33-34); dropout between the
+    layers in training mode as nn.GRU(dropout=0.3) does."""
+    h = x.transpose(0, 1)
+    for layer in range(mod.num_layers):
+        wts = []
+        for sfx in ('', '_reverse'):
+            wts += [getattr(mod, 'weight_ih_l%d%s' % (layer, sfx)), getattr(mod, 'weight_hh_l%d%s' % (layer, sfx)),
+                    getattr(mod, 'bias_ih_l%d%s' % (layer, sfx)), getattr(mod, 'bias_hh_l%d%s' % (layer, sfx))]
+        h = GruLayerFn.apply(h, *wts)
+        if training and mod.dropout > 0 and layer + 1 < mod.num_layers:
+            h = torch.nn.functional.dropout(h, mod.dropout, True)
+    return h.transpose(0, 1)
+
+
+def as_lens(lens, device):
+    """Valid-length vector as an int32 device tensor (no host sync when it already lives on the device)."""
+    if torch.is_tensor(lens) and lens.device == device:
+        return lens.to(torch.int32)
+    return torch.tensor([int(l) for l in lens], dtype=torch.int32).to(device)
+
+
+class AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, lens, scale):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, Tq, D = q.shape
+        S = k.shape[1]
+        out = torch.empty_like(q)
+        probs = torch.empty((B, Tq, S), device=q.device, dtype=torch.float32)
+        check(_lib.lib().vca_attention_fwd_f32(B, Tq, S, D, ptr(q), ptr(k), ptr(v), lens.data_ptr(), scale, ptr(out),
+                                               ptr(probs), stream()), 'attention_fwd')
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    @once
+    def backward(ctx, g):
+        q, k, v, probs = ctx.saved_tensors
+        B, Tq, D = q.shape
+        S = k.shape[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(_lib.lib().vca_attention_bwd_f32(B, Tq, S, D, ptr(_c(g)), ptr(q), ptr(k), ptr(v), ptr(probs), ctx.scale,
+                                               ptr(dq), ptr(dk), ptr(dv), stream()), 'attention_bwd')
+        return dq, dk, dv, None, None
 
 
 def masked_attention(q, k, v, lens, scale):
-    """softmax(q k^T * scale, keys >= lens[b] masked) v   (generator.py:161-167)."""
-    att = torch.bmm(q, k.transpose(1, 2)) * scale
-    S = att.shape[2]
-    lens_t = lens if (torch.is_tensor(lens) and lens.device == att.device) else \
-        torch.as_tensor([int(l) for l in lens], device=att.device)
-    pad = torch.arange(S, device=att.device)[None, None, :] >= lens_t[:, None, None]
-    att = att.masked_fill(pad, float('-inf')).softmax(2)
-    return torch.bmm(att, v)
+    """softmax(q k^T * scale, keys >= lens[b] masked) v   (generator.py:161-167); lens: int32 device tensor."""
+    assert lens.dtype == torch.int32 and lens.is_cuda
+    return AttnCoreFn.apply(q, k, v, lens, float(scale))
 
 
 def sync_loss(v_feat, a_feat, temp, gen):
