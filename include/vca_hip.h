@@ -91,6 +91,15 @@ int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, cons
 long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps);
 int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream);
 
+/* Conv3d stem of the visual front-end (nn.Conv3d(1, 64, (5,7,7), (1,2,2), (2,3,3), bias=False),
+ * visual_front.py:11) in split-bf16: x is the single-channel video [B][T][H][W], y the channels-last feature map
+ * [B][T][OH][OW][64] with OH = (H-1)/2+1.  wpack (2*64*296 bf16 = 75,776 bytes) is written by vca_stem_pack_weight
+ * from the parameter's [64][1][5][7][7] layout.  stats (128 floats, zeroed by the caller, may be NULL) receives the
+ * per-channel sum and sum of squares of y for the BatchNorm3d that follows (visual_front.py:12). */
+int vca_stem_pack_weight(const float* w, void* wpack, void* stream);
+int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, const void* wpack, float* y,
+                      float* stats, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-channel kernels on a channels-last matrix view x[P][C] (C % 4 == 0).
  * Replace nn.BatchNorm1d/2d/3d (train and eval), nn.PReLU / nn.LeakyReLU / nn.ReLU / nn.Tanh, the

@@ -11,7 +11,7 @@ def test_library_exports_declared_symbols():
     ge.build()
     from vcagan_amd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'vca_hip.h')).read()
-    declared = set(re.findall(r'\bint\s+(vca_\w+)\s*\(', hdr))
+    declared = set(re.findall(r'\b(?:int|long long)\s+(vca_\w+)\s*\(', hdr))
     assert declared, 'no declarations parsed'
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:

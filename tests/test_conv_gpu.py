@@ -130,7 +130,33 @@ def test_conv1d_linear_stem():
     yr = F.conv3d(x, wr, None, (1, 2, 2), (2, 3, 3))
     gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
     wd = w.cuda().requires_grad_(True)
-    y = ops.conv3d_stem(x.permute(0, 2, 3, 4, 1).contiguous().cuda(), wd)
+    y, _ = ops.conv3d_stem(x.permute(0, 2, 3, 4, 1).contiguous().cuda(), wd)
     assert rel_err(y, yr.permute(0, 2, 3, 4, 1)) < 2e-5
+    y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().cuda())
+    assert rel_err(wd.grad, wr.grad) < 2e-5
+
+
+@gpu
+@pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('shape', [(2, 6, 20, 24), (1, 3, 96, 96), (2, 2, 112, 104)])
+def test_stem_kernel(shape, prec, tol):
+    """Dedicated 5x7x7 stem kernel (visual_front.py:11) + its fused batch-norm statistics."""
+    from vcagan_amd import ops
+    ops.set_precision(prec)
+    B, T, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, 1, T, H, W, generator=g)
+    w = torch.randn(64, 1, 5, 7, 7, generator=g) * 0.06
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(x, wr, None, (1, 2, 2), (2, 3, 3))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    wd = torch.nn.Parameter(w.cuda())
+    y, stats = ops.conv3d_stem(x.reshape(B, T, H, W, 1).cuda(), wd)
+    yl = yr.permute(0, 2, 3, 4, 1)
+    assert y.shape == yl.shape
+    assert rel_err(y, yl) < tol
+    assert rel_err(stats[0], yl.reshape(-1, 64).sum(0)) < max(tol, 1e-4)
+    assert rel_err(stats[1], yl.reshape(-1, 64).pow(2).sum(0)) < max(tol, 1e-4)
     y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().cuda())
     assert rel_err(wd.grad, wr.grad) < 2e-5

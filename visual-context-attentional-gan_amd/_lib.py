@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
-SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip')
+SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip')
 
 
 def build(force=False, verbose=False):
@@ -49,6 +49,8 @@ _SIGS = {
     'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 7, _I),
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
+    'vca_stem_pack_weight': ([_P, _P, _P], _I),
+    'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     'vca_colstats_f32': ([_I, _I, _P, _P, _P], _I),
     'vca_bn_finalize_f32': ([_I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),

@@ -1,0 +1,210 @@
+// Conv3d stem of the visual front-end (visual_front.py:11): 1 -> 64 channels, 5x7x7 taps, stride (1,2,2), padding
+// (2,3,3), on single-channel video [B][T][H][W] -> channels-last [B][T][H/2][W/2][64], split-bf16 MFMA.
+//
+// One persistent workgroup (8 waves) walks patches of 16x16 output pixels of one frame.  The packed weights (hi/lo bf16,
+// [64][35 (kt,kh) rows x 8 kw slots], 74 KiB) are loaded into LDS once per workgroup; per patch the fp32 input halo
+// (5 frames x 37 rows x 40 columns) is prefetched into registers under the previous patch's MFMAs.  The reduction index is laid out as
+// (kt, kh, kw') with kw' = kw + 1 in 0..7 (slot 0 has zero weight), so the 8 reduction elements one MFMA lane
+// supplies are 8 CONTIGUOUS floats of a halo row (x = 2*ox - 4 + kw'): four 8-byte LDS reads, split into hi/lo
+// bf16 in registers - no im2col image is ever materialised.  Per-channel sum / sum-of-squares of the outputs (for
+// the following train-mode BatchNorm3d, visual_front.py:12) are accumulated in registers across the walk and added
+// to `stats` once per workgroup.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CO = 64, KT = 5, KH = 7, KW = 7;
+constexpr int NQ = KT * KH;          // 35 (kt,kh) rows of 8 kw slots
+constexpr int KPAD = 288;            // 36 rows * 8 (multiple of 32)
+constexpr int WROW = 296;            // bf16 elements per packed weight row (592 B: conflict-free 16-byte reads)
+constexpr int PH = 16, PW = 16;      // output patch (8 waves x 32 pixels)
+constexpr int NTHR = 512;
+constexpr int HR = 2 * (PH - 1) + KH;  // 37 halo rows
+constexpr int HC = 40;               // halo columns (2*15 + 7 + 1 = 38, padded)
+constexpr int HALO = KT * HR * HC;   // 7400 floats
+
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ dst) {
+  // dst[2][64][WROW]: hi image then lo image
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CO * WROW) return;
+  const int co = i / WROW, k = i - co * WROW;
+  float v = 0.f;
+  const int q = k >> 3, s = k & 7;
+  if (q < NQ && s >= 1) v = w[(co * NQ + q) * KW + (s - 1)];
+  const __bf16 h = (__bf16)v;
+  dst[i] = h;
+  dst[CO * WROW + i] = (__bf16)(v - (float)h);
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int W, int OH, int OW,
+                                                       const float* __restrict__ x, const __bf16* __restrict__ wp,
+                                                       float* __restrict__ y, float* __restrict__ stats,
+                                                       int tiles_y, int tiles_x, int npatch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* w_hi = reinterpret_cast<__bf16*>(smem);
+  __bf16* w_lo = w_hi + CO * WROW;
+  float* halo = reinterpret_cast<float*>(smem + (NSPLIT == 3 ? 2 : 1) * CO * WROW * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  for (int i = tid; i < (NSPLIT == 3 ? 2 : 1) * CO * WROW / 8; i += NTHR)
+    reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(wp)[i];
+
+  // this lane's output pixel inside the patch (GEMM row wave*32 + lr)
+  const int ty = wave * 2 + (lr >> 4), tx = lr & 15;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+
+  // halo staging plan of this thread: NL elements i = tid + NTHR*j, decomposed once into (kt, row, column)
+  constexpr int NL = (HALO + NTHR - 1) / NTHR;
+  int plan[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int i = tid + NTHR * j;
+    const int c = i % HC, rr = i / HC;
+    plan[j] = i < HALO ? ((rr / HR) | ((rr % HR) << 8) | (c << 16)) : -1;
+  }
+  float hv[NL];
+  auto issue = [&](int patch) {   // all loads of the patch's halo are issued back to back (kept in flight)
+    int r = patch;
+    const int tix = r % tiles_x; r /= tiles_x;
+    const int tiy = r % tiles_y; r /= tiles_y;
+    const int t = r % T;
+    const int b = r / T;
+    const int y0 = 2 * tiy * PH - 3, x0 = 2 * tix * PW - 4;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int pl = plan[j];
+      const int it = t + (pl & 255) - 2, iy = y0 + ((pl >> 8) & 255), ix = x0 + (pl >> 16);
+      float v = 0.f;
+      if (pl >= 0 && it >= 0 && it < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = x[(((size_t)b * T + it) * H + iy) * W + ix];
+      hv[j] = v;
+    }
+  };
+
+  if ((int)blockIdx.x < npatch) issue(blockIdx.x);
+  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+    int r = patch;
+    const int tix = r % tiles_x; r /= tiles_x;
+    const int tiy = r % tiles_y; r /= tiles_y;
+    const int t = r % T;
+    const int b = r / T;
+    const int oy0 = tiy * PH, ox0 = tix * PW;
+    __syncthreads();   // previous patch fully consumed (and the weights are in place on the first pass)
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      if (plan[j] >= 0) halo[tid + NTHR * j] = hv[j];
+    __syncthreads();
+    if (patch + (int)gridDim.x < npatch) issue(patch + gridDim.x);   // next halo streams in under the MFMAs
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+#pragma unroll 2
+    for (int ks = 0; ks < KPAD / 16; ++ks) {
+      const int q = ks * 2 + lh;            // (kt, kh) row this lane feeds
+      float v[8];
+      if (q < NQ) {
+        const int kt = q / KH, kh = q - kt * KH;
+        const float* src = halo + (kt * HR + 2 * ty + kh) * HC + 2 * tx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 p = *reinterpret_cast<const float2*>(src + 2 * j);
+          v[2 * j] = p.x;
+          v[2 * j + 1] = p.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      bf16x8 ah, al;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ah[j] = (__bf16)v[j];
+        al[j] = (__bf16)(v[j] - (float)ah[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = (j * 32 + lr) * WROW + ks * 16 + lh * 8;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
+        if (NSPLIT == 3) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        }
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+
+    // D[row][col]: col = lane&31 (channel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (pixel within this wave's 32)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int oy = oy0 + wave * 2 + (row >> 4), ox = ox0 + (row & 15);
+        if (oy < OH && ox < OW) {
+          const float v = acc[j][q];
+          s1[j] += v;
+          s2[j] += v * v;
+          y[((((size_t)b * T + t) * OH + oy) * OW + ox) * CO + j * 32 + lr] = v;
+        }
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = s1[j] + __shfl_xor(s1[j], 32, 64), c = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lh == 0) {
+        atomicAdd(stats + j * 32 + lr, a);
+        atomicAdd(stats + CO + j * 32 + lr, c);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vca_stem_pack_weight(const float* w, void* wpack, void* stream) {
+  VCA_CHECK_ARG(w && wpack);
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((CO * WROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<__bf16*>(wpack));
+  return vca_launch_status();
+}
+
+extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, const void* wpack, float* y,
+                                 float* stats, void* stream) {
+  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && T > 0 && H > 0 && W > 0 && x && wpack && y);
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  const int tiles_y = (OH + PH - 1) / PH, tiles_x = (OW + PW - 1) / PW;
+  const long long npatch = (long long)B * T * tiles_y * tiles_x;
+  VCA_CHECK_ARG(npatch < (1ll << 31));
+  const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + HALO * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    attr = true;
+  }
+  int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo 29 KiB)
+  if (grid > npatch) grid = (int)npatch;
+  const __bf16* wp = reinterpret_cast<const __bf16*>(wpack);
+  if (nsplit == 3)
+    hipLaunchKernelGGL(stem_fwd_kernel<3>, dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, x, wp,
+                       y, stats, tiles_y, tiles_x, (int)npatch);
+  else
+    hipLaunchKernelGGL(stem_fwd_kernel<1>, dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, x, wp,
+                       y, stats, tiles_y, tiles_x, (int)npatch);
+  return vca_launch_status();
+}

@@ -17,6 +17,7 @@ from . import _lib
 from ._lib import ConvDesc, check, ptr, stream
 
 ACT_NONE, ACT_LEAKY, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+once = torch.autograd.function.once_differentiable
 
 
 # --------------------------------------------------------------------------- #
@@ -244,17 +245,62 @@ def linear(x, w, bias=None):
     return ConvFn.apply(x2, w, bias, cfg).view(*lead, w.shape[0])
 
 
+class StemConvFn(torch.autograd.Function):
+    """The 5x7x7 stride-(1,2,2) stem on the dedicated split-bf16 kernel; also returns the per-channel
+    (sum, sum of squares) of its output for the batch-norm that follows."""
+
+    @staticmethod
+    def forward(ctx, x, w, cfg):
+        x = _c(x)
+        B, T, H, W, _ = x.shape
+        L = _lib.lib()
+        key = 20
+        wp = None
+        cacheable = isinstance(w, torch.nn.Parameter)
+        if cacheable:
+            ent = _pack_cache.get(id(w))
+            if ent is not None and ent[0]() is w and ent[1].get(key, (None,))[0] == (w._version, _param_epoch[0]):
+                wp = ent[1][key][1]
+        if wp is None:
+            wp = torch.empty(2 * 64 * 296 * 2, device=x.device, dtype=torch.uint8)
+            check(L.vca_stem_pack_weight(ptr(_c(w.detach())), wp.data_ptr(), stream()), 'stem_pack')
+            if cacheable:
+                k2 = id(w)
+                ent = _pack_cache.get(k2)
+                if ent is None or ent[0]() is not w:
+                    ent = (weakref.ref(w, lambda _r, k2=k2: _pack_cache.pop(k2, None)), {})
+                    _pack_cache[k2] = ent
+                ent[1][key] = ((w._version, _param_epoch[0]), wp)
+        y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
+        stats = torch.zeros((2, 64), device=x.device, dtype=torch.float32)
+        check(L.vca_stem_fwd_bf16(_nsplit(), B, T, H, W, ptr(x), wp.data_ptr(), ptr(y), ptr(stats), stream()),
+              'stem_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once
+    def backward(ctx, gy, _gstats):
+        x, w = ctx.saved_tensors
+        gw = _conv_wgrad_raw(x, _c(gy), ctx.cfg) if ctx.needs_input_grad[1] else None
+        return None, gw, None
+
+
 def conv3d_stem(x, w, stride=2, pad=(2, 3, 3)):
-    """x: (N,D,H,W,1); w: (Cout,1,KD,KH,KW), spatial stride `stride`, temporal stride 1 (visual_front.py:11)."""
+    """x: (N,D,H,W,1); w: (64,1,5,7,7), spatial stride 2, temporal stride 1 (visual_front.py:11).
+    Returns (y, stats): stats is None or the per-channel (sum, sum of squares) of y."""
     cfg = ConvCfg(w.shape, x.shape, stride, (pad[1], pad[2]), 0, pad_d=pad[0])
-    return ConvFn.apply(x, w, None, cfg)
+    if _nsplit() and tuple(w.shape) == (64, 1, 5, 7, 7) and stride == 2 and tuple(pad) == (2, 3, 3):
+        return StemConvFn.apply(x, w, cfg)
+    return ConvFn.apply(x, w, None, cfg), None
 
 
 # --------------------------------------------------------------------------- #
 # per-channel kernels: batch-norm + activation, activations, residual scale-add
 # --------------------------------------------------------------------------- #
 LEAKY = 'leaky0.2'      # the generator/discriminator activation (generator.py:9,52,95: nn.LeakyReLU(0.2))
-once = torch.autograd.function.once_differentiable
 
 
 def _act_code(act):
@@ -317,18 +363,23 @@ class BnActFn(torch.autograd.Function):
         return gx, ggamma, gbeta, galpha, gres, None, None, None, None, None
 
 
-def _bn_coef(x, bn):
-    """Batch-norm coefficients (mean, invstd, scale, shift) for a channels-last tensor; updates running stats."""
+def _bn_coef(x, bn, stats=None):
+    """Batch-norm coefficients (mean, invstd, scale, shift) for a channels-last tensor; updates running stats.
+    `stats`: optional precomputed per-channel (sum, sum of squares) of x (from a convolution epilogue)."""
     P, C = _pc(x)
     coef = torch.empty((4, C), device=x.device, dtype=torch.float32)
     L = _lib.lib()
     if bn.training or bn.running_mean is None:
-        sums = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-        xd = _c(x.detach())
-        check(L.vca_colstats_f32(P, C, ptr(xd), ptr(sums), stream()), 'colstats')
+        pivot = None
+        if stats is None:
+            sums = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+            pivot = _c(x.detach())
+            check(L.vca_colstats_f32(P, C, ptr(pivot), ptr(sums), stream()), 'colstats')
+        else:
+            sums = stats
         mom = bn.momentum if bn.momentum is not None else 0.1
         track = bn.training and bn.track_running_stats and bn.running_mean is not None
-        check(L.vca_bn_finalize_f32(C, float(P), ptr(sums), ptr(xd), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+        check(L.vca_bn_finalize_f32(C, float(P), ptr(sums), ptr(pivot), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                                     bn.eps, mom, ptr(bn.running_mean) if track else None,
                                     ptr(bn.running_var) if track else None,
                                     ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
@@ -341,10 +392,10 @@ def _bn_coef(x, bn):
     return coef, False
 
 
-def bn_act(x, bn, act=None, residual=None):
+def bn_act(x, bn, act=None, residual=None, stats=None):
     """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor."""
     code, slope, alpha = _act_code(act)
-    coef, train = _bn_coef(x, bn)
+    coef, train = _bn_coef(x, bn, stats)
     return BnActFn.apply(x, bn.weight, bn.bias, alpha, residual, coef, code, slope, 1.0, train)
 
 
