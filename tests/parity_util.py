@@ -22,7 +22,7 @@ def close(a, b, atol=1e-5, rtol=1e-5):
     np.testing.assert_allclose(to_np(a), b, atol=atol, rtol=rtol)
 
 
-def check_step(models, res, g, s, loss_rtol, out_atol, grad_rel, param_p90):
+def check_step(models, res, g, s, loss_rtol, out_atol, grad_rel, param_p90, skip_grads=()):
     """Compare one GAN step with the golden.
 
     Gradients of this network are discontinuous in the activations (LeakyReLU/PReLU kinks, max-pool argmax, L1
@@ -30,6 +30,10 @@ def check_step(models, res, g, s, loss_rtol, out_atol, grad_rel, param_p90):
     ~10 % at step 1 (measured on the CPU oracle against itself), so gradients are compared as a relative L2 error
     over each module's sampled entries, and parameters after Adam - whose first steps move every weight by
     lr*sign(grad) - by the distribution of absolute differences.
+
+    skip_grads: modules whose .grad is not compared.  After a step the reference's discriminators hold the
+    gradient of gen_loss, which it never uses (d_optimizer.zero_grad() runs before the next D backward,
+    train.py:209); the HIP step does not compute it.  Their parameters after Adam are still compared.
     """
     for k in LOSS_KEYS:
         want = float(g['s%d:%s' % (s, k)])
@@ -44,10 +48,12 @@ def check_step(models, res, g, s, loss_rtol, out_atol, grad_rel, param_p90):
         for pname, p in models[mod].named_parameters():
             idx = fixtures.sample_idx(p.numel(), 8, mod + '.' + pname)
             pdiff.append(np.abs(to_np(p).reshape(-1)[idx] - g['s%d:param:%s:%s' % (s, mod, pname)]))
-            if p.grad is not None:
+            if p.grad is not None and mod not in skip_grads:
                 gn += float(p.grad.double().pow(2).sum())
                 got.append(to_np(p.grad).reshape(-1)[idx])
                 want.append(g['s%d:grad:%s:%s' % (s, mod, pname)])
+        if mod in skip_grads:
+            continue
         got, want = np.concatenate(got), np.concatenate(want)
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
         assert rel <= grad_rel, (s, mod, rel)

@@ -77,8 +77,8 @@ class GenResBlk(nn.Module):
 
     def forward(self, x):
         ups = 1 if self.upsample else 0
-        r = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups)      # nearest x2 read inside the conv
-        r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
+        r, st = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups, want_stats=True)   # nearest x2 read inside the conv
+        r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY, stats=st), self.conv2)
         if self.learned_sc:
             s = _conv(x, self.conv1x1, ups)
         else:
@@ -137,8 +137,8 @@ class Postnet(nn.Module):
     def forward(self, x):                                      # (B, 1, 80, T)
         p = self.postnet
         h = x.squeeze(1).transpose(1, 2).contiguous()          # (B, T, 80)
-        h = ops.conv1d(h, p[0].weight, p[0].bias, 3)
-        h = ops.bn_act(h, p[1], ops.LEAKY)
+        h, st = ops.conv1d(h, p[0].weight, p[0].bias, 3, want_stats=True)
+        h = ops.bn_act(h, p[1], ops.LEAKY, stats=st)
         h = p[5](p[4](p[3](h)))
         h = ops.conv1d(h, p[6].weight, None, 0)                # (B, T, 321)
         return h.transpose(1, 2).unsqueeze(1)                  # (B, 1, 321, T)
@@ -250,7 +250,8 @@ class sync_Discriminator(nn.Module):
         fe = self.frontend
         a = _conv(aud.reshape(B, aud.size(2), aud.size(3), 1), fe[0])
         a = ops.bn_act(a, fe[1], fe[2])
-        a = ops.bn_act(_conv(a, fe[3]), fe[4], fe[5])
+        a, st = _conv(a, fe[3], want_stats=True)
+        a = ops.bn_act(a, fe[4], fe[5], stats=st)
         a = self.Res_block(a)                                             # (B, 20, S, 256)
         b, f, t, ch = a.shape
         a = a.permute(0, 2, 3, 1).reshape(b, t, ch * f)                   # feature index c*F + f (generator.py:344)

@@ -39,15 +39,15 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = ops.conv2d(x, self.conv1.weight, None, self.stride, 1)
-        y = ops.bn_act(y, self.bn1, self.relu1)
-        y = ops.conv2d(y, self.conv2.weight, None, 1, 1)
+        y, st = ops.conv2d(x, self.conv1.weight, None, self.stride, 1, want_stats=True)
+        y = ops.bn_act(y, self.bn1, self.relu1, stats=st)
+        y, st = ops.conv2d(y, self.conv2.weight, None, 1, 1, want_stats=True)
         if self.downsample is not None:
-            sc = ops.conv2d(x, self.downsample[0].weight, None, self.downsample[0].stride[0], 0)
-            sc = ops.bn_act(sc, self.downsample[1], None)
+            sc, st2 = ops.conv2d(x, self.downsample[0].weight, None, self.downsample[0].stride[0], 0, want_stats=True)
+            sc = ops.bn_act(sc, self.downsample[1], None, stats=st2)
         else:
             sc = x
-        return ops.bn_act(y, self.bn2, self.relu2, residual=sc)
+        return ops.bn_act(y, self.bn2, self.relu2, residual=sc, stats=st)
 
 
 class ResNet(nn.Module):

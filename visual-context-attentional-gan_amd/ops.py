@@ -121,16 +121,17 @@ def _nsplit():
     return {'fp32': 0, 'bf16x3': 3, 'bf16': 1}[_precision[0]]
 
 
-def _conv_fwd_raw(x, w, bias, cfg):
+def _conv_fwd_raw(x, w, bias, cfg, stats=None):
+    """stats: optional zeroed (2, Cout) tensor receiving per-channel sum / sum of squares of (y - bias)."""
     y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
     d = cfg.desc()
     ns = _nsplit()
     if ns and cfg.cin > 1 and cfg.kd == 1:
         check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
-                                           ptr(y), None, stream()), 'conv_fwd_bf16')
+                                           ptr(y), ptr(stats), stream()), 'conv_fwd_bf16')
     else:
         check(_lib.lib().vca_conv_fwd_f32(d, ptr(x), ptr(_pack(w, 0)), ptr(bias), None, None, None, None, ptr(y),
-                                          None, stream()), 'conv_fwd')
+                                          ptr(stats), stream()), 'conv_fwd')
     return y
 
 
@@ -167,6 +168,32 @@ def _conv_wgrad_raw(x, gy, cfg):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+class ConvStatsFn(torch.autograd.Function):
+    """Convolution that also returns the per-channel (sum, sum of squares) of its bias-free output, produced in the
+    kernel epilogue, so the train-mode batch-norm that follows needs no statistics pass over the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cfg):
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        stats = torch.zeros((2, cfg.cout), device=x.device, dtype=torch.float32)
+        y = _conv_fwd_raw(_c(x), w, bias, cfg, stats)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once
+    def backward(ctx, gy, _gs):
+        x, w = ctx.saved_tensors
+        cfg = ctx.cfg
+        gy = _c(gy)
+        gx = _conv_dgrad_raw(gy, w, cfg) if ctx.needs_input_grad[0] else None
+        gw = _conv_wgrad_raw(_c(x), gy, cfg) if ctx.needs_input_grad[1] else None
+        gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -222,17 +249,32 @@ class ConvWgradFn(torch.autograd.Function):
         return gx, ggy, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, ups=0):
-    """x: (N,H,W,Cin) channels-last; w: (Cout,Cin,KH,KW).  Returns (N,OH,OW,Cout)."""
+class BnStats:
+    """Statistics of a convolution output handed to the batch-norm that follows: sums of (y - bias)."""
+
+    def __init__(self, sums, bias):
+        self.sums, self.bias = sums, bias
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, ups=0, want_stats=False):
+    """x: (N,H,W,Cin) channels-last; w: (Cout,Cin,KH,KW).  Returns (N,OH,OW,Cout); with want_stats also a BnStats
+    for ops.bn_act(..., stats=)."""
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
     cfg = ConvCfg(w.shape, x.shape, stride, pad, ups)
-    return ConvFn.apply(x, w, bias, cfg)
+    if want_stats and cfg.cin > 1:
+        y, sums = ConvStatsFn.apply(x, w, bias, cfg)
+        return y, BnStats(sums, bias)
+    y = ConvFn.apply(x, w, bias, cfg)
+    return (y, None) if want_stats else y
 
 
-def conv1d(x, w, bias=None, pad=0):
+def conv1d(x, w, bias=None, pad=0, want_stats=False):
     """x: (N,L,Cin); w: (Cout,Cin,K).  Returns (N,L',Cout)."""
     n, l, c = x.shape
     cfg = ConvCfg((w.shape[0], w.shape[1], 1, w.shape[2]), (n, 1, l, c), 1, (0, pad), 0, pshape=w.shape)
+    if want_stats:
+        y, sums = ConvStatsFn.apply(x.reshape(n, 1, l, c), w, bias, cfg)
+        return y.view(n, cfg.ow, w.shape[0]), BnStats(sums, bias)
     y = ConvFn.apply(x.reshape(n, 1, l, c), w, bias, cfg)
     return y.view(n, cfg.ow, w.shape[0])
 
@@ -375,6 +417,9 @@ def _bn_coef(x, bn, stats=None):
             sums = torch.zeros((2, C), device=x.device, dtype=torch.float32)
             pivot = _c(x.detach())
             check(L.vca_colstats_f32(P, C, ptr(pivot), ptr(sums), stream()), 'colstats')
+        elif isinstance(stats, BnStats):
+            sums = stats.sums
+            pivot = stats.bias.detach() if stats.bias is not None else None
         else:
             sums = stats
         mom = bn.momentum if bn.momentum is not None else 0.1

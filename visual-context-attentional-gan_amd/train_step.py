@@ -116,6 +116,11 @@ class GanStep:
         self.d_opt.step()
 
         # ---- generator phase (train.py:215-237)
+        # The reference also back-propagates gen_loss into the discriminators' weights and throws those gradients
+        # away (d_optimizer.zero_grad() precedes their next use, train.py:209); here they are simply not computed.
+        d_params = [p for n in D_NAMES for p in m[n].parameters()]
+        for p in d_params:
+            p.requires_grad_(False)
         gs = m['post'](g3)
         gen_lo = [d(g, sd, T) for d, g in zip(dis, (g1, g2, g3))]
         g_sync = m['s_dis'](phon.detach(), g3, gen=True).mean()
@@ -132,6 +137,8 @@ class GanStep:
             gen_loss = g_loss + 50.0 * recon + g_sync
         self._zero(D_NAMES + ('gen', 'post'))
         gen_loss.backward()
+        for p in d_params:
+            p.requires_grad_(True)
         self.g_exchange.reduce()
         self.g_opt.step()
         return dict(dis_loss=dis_loss.detach(), gen_loss=gen_loss.detach(), sync_loss=sync_loss.detach(),
