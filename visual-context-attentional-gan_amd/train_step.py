@@ -15,6 +15,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import ops
+from .grad_exchange import GradExchange
 from .models import generator as G
 from .models.visual_front import Visual_front
 
@@ -50,23 +51,6 @@ def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
 def denormalize(m):
     """Log-mel de-normalisation of src/data/vid_aud_grid.py:238-240."""
     return (m + 1.0) * (-_LOG_EPS / 2.0) + _LOG_EPS
-
-
-class GradExchange:
-    """Mean all-reduce of flat gradient buffers (one RCCL call per module, issued back to back and waited together)."""
-
-    def __init__(self, gflats, group=None):
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.gflats = list(gflats)
-
-    def reduce(self):
-        if self.world == 1:
-            return
-        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for g in self.gflats]
-        for w, g in zip(works, self.gflats):
-            w.wait()
-            g.mul_(1.0 / self.world)
 
 
 class GanStep:
