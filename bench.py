@@ -168,7 +168,7 @@ def main():
             'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                    'weights' % args.batch, 'global_batch': args.batch * world,
                        'parallelism': 'dp%d' % world},
-            'step_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
+            'ref_algorithmic_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
             'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
         }
         res['roofline'] = roofline_probe(device, dtype)

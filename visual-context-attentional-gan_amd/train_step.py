@@ -83,7 +83,12 @@ class GanStep:
 
         # ---- discriminator phase (train.py:182-211)
         real_lo = [d(r, sd, T) for d, r in zip(dis, reals)]
-        sync_loss = m['s_dis'](phon, reals[2]).mean()
+        # The sync loss is the only D-phase term that reaches v_front (train.py:186,210 "accumulate v_front grad").
+        # Back-propagation is linear in the incoming gradient, so instead of running v_front's backward twice (once
+        # per phase) the D phase stops at the phoneme features and their gradient is added to the G phase's before
+        # v_front is traversed once: v_front.grad = J^T (g_D + g_G) = J^T g_D + J^T g_G.
+        phon_d = phon.detach().requires_grad_(True)
+        sync_loss = m['s_dis'](phon_d, reals[2]).mean()
         grad_p = []
         for (u, _), r in zip(real_lo, reals):
             gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
@@ -95,7 +100,7 @@ class GanStep:
                      + sum(G.gan_loss(c, False) for _, c in fake_lo)) / 3
         dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
         self._zero(D_NAMES)
-        dis_loss.backward(retain_graph=True)          # also accumulates the sync-loss gradient into v_front
+        dis_loss.backward()
         self.d_exchange.reduce()
         self.d_opt.step()
 
@@ -120,7 +125,7 @@ class GanStep:
             recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, spec)
             gen_loss = g_loss + 50.0 * recon + g_sync
         self._zero(D_NAMES + ('gen', 'post'))
-        gen_loss.backward()
+        torch.autograd.backward([gen_loss, phon], [None, phon_d.grad])
         for p in d_params:
             p.requires_grad_(True)
         self.g_exchange.reduce()
