@@ -174,6 +174,12 @@ int vca_gru_cell_bwd_f32(int B, int H, const float* dout, int dout_stride, const
                          const float* save, const float* h_prev, float* d_gi, float* d_gh, float* dh_direct,
                          void* stream);
 
+/* Latency-oriented GEMM for the recurrent products: y_i[M][N] = x_i[M][K] . W_i^T (+ bias_i) for nprob = 1 or 2
+ * independent problems of the same shape in one launch (the two directions of a bidirectional layer).
+ * w_i: the split-bf16 layout of vca_pack_weight_bf16 for a (N, K) [mode 0] or (K, N) [mode 1] weight with 1 tap. */
+int vca_skinny_gemm_bf16(int nsplit, int nprob, int M, int N, int K, const float* x0, const float* x1, const void* w0,
+                         const void* w1, const float* b0, const float* b1, float* y0, float* y1, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses and optimiser.
  * ---------------------------------------------------------------------------------------------- */

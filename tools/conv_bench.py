@@ -23,7 +23,7 @@ orig = {k: getattr(ops, k) for k in ('_conv_fwd_raw', '_conv_dgrad_raw', '_conv_
 
 def rec(kind):
     def f(a, b, *rest):
-        cfg = rest[-1]
+        cfg = [r for r in rest if isinstance(r, ops.ConvCfg)][0]
         key = (kind, cfg.xshape, cfg.wshape, cfg.stride, cfg.pad_h, cfg.pad_w, cfg.ups)
         seen[key] = seen.get(key, 0) + 1
         return orig['_conv_%s_raw' % kind](a, b, *rest)

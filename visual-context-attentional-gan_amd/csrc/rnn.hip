@@ -76,3 +76,101 @@ extern "C" int vca_gru_cell_bwd_f32(int B, int H, const float* dout, int dout_st
                      dout_stride, dh_a, dh_b, save, h_prev, d_gi, d_gh, dh_direct);
   return vca_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM for the recurrent step: y[M<=32*gy][N] = x[M][K] . W^T (+ bias), split-bf16, for up to two
+// independent problems per launch (the two directions of a bidirectional layer: blockIdx.z).
+// A 75-step recurrence is latency-bound, so the kernel is built for the shortest dependent chain rather than for
+// throughput: no LDS staging and no barriers in the main loop - each wave takes a quarter of the reduction, loads
+// its A rows straight from global memory (fp32 -> hi/lo bf16 in registers) and its B fragments straight from the
+// L2-resident packed weights ([32-deep slice][row][hi 32 | lo 32] bf16, the layout of vca_pack_weight_bf16); the
+// four partial 32x32 tiles meet in LDS once at the end.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct SkinnyArgs {
+  const float* x[2];
+  const unsigned char* w[2];
+  const float* bias[2];
+  float* y[2];
+  int M, N, K, npad, nsplit;
+};
+
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int z = blockIdx.z, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const float* x = a.x[z];
+  const unsigned char* w = a.w[z];
+  const int nks = (a.K + 15) / 16;
+  const int per = (nks + 3) / 4;
+  const int ks_beg = wave * per, ks_end = min(nks, ks_beg + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int row = m0 + lr;
+  const bool rv = row < a.M;
+  const bool vec = (a.K % 4) == 0;
+  for (int ks = ks_beg; ks < ks_end; ++ks) {
+    const int k0 = ks * 16 + lh * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rv) {
+      const float* src = x + (size_t)row * a.K + k0;
+      if (vec && k0 + 8 <= a.K) {
+        const float4 p = *reinterpret_cast<const float4*>(src), q = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < a.K) v[j] = src[j];
+      }
+    }
+    bf16x8 ah, al;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ah[j] = (__bf16)v[j];
+      al[j] = (__bf16)(v[j] - (float)ah[j]);
+    }
+    // weight row n0+lr of slice ks>>1: 128 B = [hi 32 | lo 32]; this lane's 8 values start at (ks&1)*16 + lh*8
+    const unsigned char* wp = w + ((size_t)(ks >> 1) * a.npad + n0 + lr) * 128 + ((ks & 1) * 16 + lh * 8) * 2;
+    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
+    if (a.nsplit == 3) {
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + 64);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    const int m = m0 + r, n = n0 + c;
+    if (m < a.M && n < a.N) {
+      float s = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
+      if (a.bias[z]) s += a.bias[z][n];
+      a.y[z][(size_t)m * a.N + n] = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vca_skinny_gemm_bf16(int nsplit, int nprob, int M, int N, int K, const float* x0, const float* x1,
+                                    const void* w0, const void* w1, const float* b0, const float* b1, float* y0,
+                                    float* y1, void* stream) {
+  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && (nprob == 1 || nprob == 2) && M > 0 && N > 0 && K > 0);
+  VCA_CHECK_ARG(x0 && w0 && y0 && (nprob == 1 || (x1 && w1 && y1)));
+  SkinnyArgs a;
+  a.x[0] = x0; a.x[1] = x1;
+  a.w[0] = reinterpret_cast<const unsigned char*>(w0); a.w[1] = reinterpret_cast<const unsigned char*>(w1);
+  a.bias[0] = b0; a.bias[1] = b1;
+  a.y[0] = y0; a.y[1] = y1;
+  a.M = M; a.N = N; a.K = K; a.npad = (N + 31) / 32 * 32; a.nsplit = nsplit;
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(256), 0, (hipStream_t)stream,
+                     a);
+  return vca_launch_status();
+}

@@ -695,9 +695,28 @@ def _gemm_tn(x2d, gy2d, w):
     return _conv_wgrad_raw(x2d, gy2d, _lin_cfg(w, x2d.shape[0]))
 
 
+def _rec_gemm(xs, ws, biases, mode):
+    """The recurrent products of the two directions of a layer in one launch: y_i = x_i @ W_i^T + b_i (mode 0) or
+    y_i = x_i @ W_i (mode 1, the input gradient).  Exact-fp32 precision falls back to the general GEMM path."""
+    ns = _nsplit()
+    if not ns:
+        if mode == 0:
+            return [_gemm_nt(x, w, b) for x, w, b in zip(xs, ws, biases)]
+        return [_gemm_nn(x, w) for x, w in zip(xs, ws)]
+    M, K = xs[0].shape
+    N = ws[0].shape[0] if mode == 0 else ws[0].shape[1]
+    ys = [torch.empty((M, N), device=xs[0].device, dtype=torch.float32) for _ in xs]
+    packs = [_pack(w, 10 + mode) for w in ws]
+    check(_lib.lib().vca_skinny_gemm_bf16(ns, 2, M, N, K, ptr(xs[0]), ptr(xs[1]), packs[0].data_ptr(),
+                                          packs[1].data_ptr(), ptr(biases[0]), ptr(biases[1]), ptr(ys[0]),
+                                          ptr(ys[1]), stream()), 'skinny_gemm')
+    return ys
+
+
 class GruLayerFn(torch.autograd.Function):
-    """One bidirectional GRU layer over a time-major sequence: x (T,B,I) -> (T,B,2H).  The gate GEMMs run on the
-    matrix-core kernels, the gate arithmetic in vca_gru_cell_*; backward is explicit back-propagation through time."""
+    """One bidirectional GRU layer over a time-major sequence: x (T,B,I) -> (T,B,2H).  The input-gate GEMMs of all
+    time steps run on the matrix-core convolution kernels, the per-step recurrent products of both directions share
+    one latency-oriented launch, the gate arithmetic is vca_gru_cell_*; backward is explicit BPTT."""
 
     @staticmethod
     def forward(ctx, x, *wts):
@@ -705,26 +724,24 @@ class GruLayerFn(torch.autograd.Function):
         T, B, I = x.shape
         H = wts[1].shape[1]
         L = _lib.lib()
-        out = torch.empty((T, B, 2 * H), device=x.device, dtype=torch.float32)
+        dev = x.device
+        out = torch.empty((T, B, 2 * H), device=dev, dtype=torch.float32)
         x2 = x.view(T * B, I)
-        saved = []
-        for d in range(2):
-            w_ih, w_hh, b_ih, b_hh = wts[4 * d:4 * d + 4]
-            gi = _gemm_nt(x2, w_ih, b_ih).view(T, B, 3 * H)
-            hbuf = torch.empty((T, B, H), device=x.device, dtype=torch.float32)
-            save = torch.empty((T, B, 4 * H), device=x.device, dtype=torch.float32)
-            h0 = torch.zeros((B, H), device=x.device, dtype=torch.float32)
-            order = range(T) if d == 0 else range(T - 1, -1, -1)
-            prev = None
-            for t in order:
-                hp = h0 if prev is None else hbuf[prev]
-                gh = _gemm_nt(hp, w_hh, b_hh)
-                check(L.vca_gru_cell_fwd_f32(B, H, ptr(gi[t]), ptr(gh), ptr(hp), ptr(hbuf[t]),
-                                             out[t].data_ptr() + 4 * d * H, 2 * H, ptr(save[t]), stream()),
+        gi = [_gemm_nt(x2, wts[4 * d], wts[4 * d + 2]).view(T, B, 3 * H) for d in range(2)]
+        hbuf = [torch.empty((T, B, H), device=dev, dtype=torch.float32) for _ in range(2)]
+        save = [torch.empty((T, B, 4 * H), device=dev, dtype=torch.float32) for _ in range(2)]
+        h0 = torch.zeros((B, H), device=dev, dtype=torch.float32)
+        w_hh, b_hh = [wts[1], wts[5]], [wts[3], wts[7]]
+        for s in range(T):
+            ts = (s, T - 1 - s)
+            hp = [h0 if s == 0 else hbuf[0][s - 1], h0 if s == 0 else hbuf[1][T - s]]
+            gh = _rec_gemm(hp, w_hh, b_hh, 0)
+            for d in range(2):
+                t = ts[d]
+                check(L.vca_gru_cell_fwd_f32(B, H, ptr(gi[d][t]), ptr(gh[d]), ptr(hp[d]), ptr(hbuf[d][t]),
+                                             out[t].data_ptr() + 4 * d * H, 2 * H, ptr(save[d][t]), stream()),
                       'gru_cell_fwd')
-                prev = t
-            saved += [hbuf, save]
-        ctx.save_for_backward(x, *wts, *saved)
+        ctx.save_for_backward(x, *wts, hbuf[0], save[0], hbuf[1], save[1])
         return out
 
     @staticmethod
@@ -732,35 +749,39 @@ class GruLayerFn(torch.autograd.Function):
     def backward(ctx, dout):
         x = ctx.saved_tensors[0]
         wts = ctx.saved_tensors[1:9]
-        saved = ctx.saved_tensors[9:]
+        hbuf = [ctx.saved_tensors[9], ctx.saved_tensors[11]]
+        save = [ctx.saved_tensors[10], ctx.saved_tensors[12]]
         dout = _c(dout)
         T, B, I = x.shape
         H = wts[1].shape[1]
         L = _lib.lib()
+        dev = x.device
         x2 = x.view(T * B, I)
+        zeros = torch.zeros((1, B, H), device=dev, dtype=torch.float32)
+        # h_prev(t): the state the step at time t started from
+        hprev = [torch.cat([zeros, hbuf[0][:-1]], 0), torch.cat([hbuf[1][1:], zeros], 0)]
+        d_gi = [torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32) for _ in range(2)]
+        d_gh = [torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32) for _ in range(2)]
+        w_hh = [wts[1], wts[5]]
+        dh_gemm, dh_dir = [None, None], [None, None]
+        for s in range(T):
+            ts = (T - 1 - s, s)
+            for d in range(2):
+                t = ts[d]
+                nd = torch.empty((B, H), device=dev, dtype=torch.float32)
+                check(L.vca_gru_cell_bwd_f32(B, H, dout[t].data_ptr() + 4 * d * H, 2 * H, ptr(dh_gemm[d]),
+                                             ptr(dh_dir[d]), ptr(save[d][t]), ptr(hprev[d][t]), ptr(d_gi[d][t]),
+                                             ptr(d_gh[d][t]), ptr(nd), stream()), 'gru_cell_bwd')
+                dh_dir[d] = nd
+            if s + 1 < T:
+                dh_gemm = _rec_gemm([d_gh[0][ts[0]], d_gh[1][ts[1]]], w_hh, [None, None], 1)
         dx = None
         grads = []
         for d in range(2):
-            w_ih, w_hh, b_ih, b_hh = wts[4 * d:4 * d + 4]
-            hbuf, save = saved[2 * d], saved[2 * d + 1]
-            d_gi = torch.empty((T, B, 3 * H), device=x.device, dtype=torch.float32)
-            d_gh = torch.empty((T, B, 3 * H), device=x.device, dtype=torch.float32)
-            zeros = torch.zeros((1, B, H), device=x.device, dtype=torch.float32)
-            # h_{prev}(t): the state the step at time t started from
-            hprev_all = torch.cat([zeros, hbuf[:-1]], 0) if d == 0 else torch.cat([hbuf[1:], zeros], 0)
-            order = range(T - 1, -1, -1) if d == 0 else range(T)
-            dh_gemm, dh_dir = None, None
-            for t in order:
-                nd = torch.empty((B, H), device=x.device, dtype=torch.float32)
-                check(L.vca_gru_cell_bwd_f32(B, H, dout[t].data_ptr() + 4 * d * H, 2 * H, ptr(dh_gemm), ptr(dh_dir),
-                                             ptr(save[t]), ptr(hprev_all[t]), ptr(d_gi[t]), ptr(d_gh[t]), ptr(nd),
-                                             stream()), 'gru_cell_bwd')
-                dh_dir = nd
-                dh_gemm = _gemm_nn(d_gh[t], w_hh)
-            gi2, gh2 = d_gi.view(T * B, 3 * H), d_gh.view(T * B, 3 * H)
-            g_w_ih = _gemm_tn(x2, gi2, w_ih)
-            g_w_hh = _gemm_tn(hprev_all.view(T * B, H), gh2, w_hh)
-            grads += [g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0)]
+            w_ih = wts[4 * d]
+            gi2, gh2 = d_gi[d].view(T * B, 3 * H), d_gh[d].view(T * B, 3 * H)
+            grads += [_gemm_tn(x2, gi2, w_ih), _gemm_tn(hprev[d].view(T * B, H), gh2, w_hh[d]), gi2.sum(0),
+                      gh2.sum(0)]
             if ctx.needs_input_grad[0]:
                 part = _gemm_nn(gi2, w_ih)
                 dx = part if dx is None else dx + part
