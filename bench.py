@@ -22,8 +22,8 @@ if ROOT not in sys.path:
 
 B, T, H = 32, 75, 96
 FLOP_PER_FRAME = 9.84e9          # full step at 96x96, counted on the reference with torch's FlopCounterMode
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0}
-MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3}
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'mixed': 2500.0}
+MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'mixed': 3}
 
 
 def synth(b, t, h, device, seed):
@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--batch', type=int, default=B)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
-    ap.add_argument('--precision', default='bf16x3', choices=['fp32', 'bf16x3', 'bf16'])
+    ap.add_argument('--precision', default='bf16x3', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

@@ -100,7 +100,7 @@ def test_avgpool_window_rule(name):
 
 
 @gpu
-@pytest.mark.parametrize('prec', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'mixed'])
 @pytest.mark.parametrize('variant', ['grid', 'lrs'])
 def test_step_matches_reference(variant, prec):
     from vcagan_amd import ops, train_step

@@ -40,8 +40,10 @@ _precision = ['fp32']
 
 def set_precision(mode):
     """Arithmetic of the matrix-core convolutions: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, three bf16 MFMAs
-    per product, fp32 accumulate: ~fp32 accuracy) or 'bf16' (single bf16 product)."""
-    assert mode in ('fp32', 'bf16x3', 'bf16')
+    per product, fp32 accumulate: ~fp32 accuracy), 'bf16' (single bf16 product) or 'mixed' (bf16x3 in every forward
+    product, so outputs keep fp32-level parity, and single bf16 products in the input/weight gradients, as bf16
+    mixed-precision training does)."""
+    assert mode in ('fp32', 'bf16x3', 'bf16', 'mixed')
     _precision[0] = mode
 
 
@@ -117,7 +119,12 @@ class ConvCfg:
                         self.stride, 0, 0, 0.0, 1.0)
 
 
-def _nsplit():
+_exact_bwd = [False]   # True while a backward runs under create_graph (its results feed a loss value: R1 penalty)
+
+
+def _nsplit(backward=False):
+    if _precision[0] == 'mixed':
+        return 1 if (backward and not _exact_bwd[0]) else 3
     return {'fp32': 0, 'bf16x3': 3, 'bf16': 1}[_precision[0]]
 
 
@@ -139,7 +146,7 @@ def _conv_dgrad_raw(gy, w, cfg):
     he, we = cfg.hin << cfg.ups, cfg.win << cfg.ups
     gx = torch.empty((cfg.n, he, we, cfg.cin), device=gy.device, dtype=torch.float32)
     d = cfg.dgrad_desc()
-    ns = _nsplit()
+    ns = _nsplit(True)
     if ns and cfg.cout > 1:
         check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, None,
                                            ptr(gx), None, stream()), 'conv_dgrad_bf16')
@@ -154,7 +161,7 @@ def _conv_dgrad_raw(gy, w, cfg):
 def _conv_wgrad_raw(x, gy, cfg):
     cout, cin, taps = cfg.cout, cfg.cin, cfg.kd * cfg.kh * cfg.kw
     dwp = torch.zeros((taps, cin, (cout + 3) // 4 * 4), device=x.device, dtype=torch.float32)
-    ns = _nsplit()
+    ns = _nsplit(True)
     if ns and cin > 1 and cfg.kd == 1 and taps <= 32:
         check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
               'conv_wgrad_bf16')
@@ -209,8 +216,10 @@ class ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         cfg = ctx.cfg
         gy = _c(gy)
+        _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, w, cfg) if ctx.needs_input_grad[0] else None
         gw = ConvWgradFn.apply(x, gy, cfg) if ctx.needs_input_grad[1] else None
+        _exact_bwd[0] = False
         gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
@@ -227,8 +236,10 @@ class ConvDgradFn(torch.autograd.Function):
         gy, w = ctx.saved_tensors
         cfg = ctx.cfg
         ggx = _c(ggx)
+        _exact_bwd[0] = torch.is_grad_enabled()
         ggy = ConvFn.apply(ggx, w, None, cfg) if ctx.needs_input_grad[0] else None
         gw = ConvWgradFn.apply(ggx, gy, cfg) if ctx.needs_input_grad[1] else None
+        _exact_bwd[0] = False
         return ggy, gw, None
 
 
@@ -244,8 +255,10 @@ class ConvWgradFn(torch.autograd.Function):
         x, gy = ctx.saved_tensors
         cfg = ctx.cfg
         ggw = _c(ggw)
+        _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, ggw, cfg) if ctx.needs_input_grad[0] else None
         ggy = ConvFn.apply(x, ggw, None, cfg) if ctx.needs_input_grad[1] else None
+        _exact_bwd[0] = False
         return gx, ggy, None
 
 
