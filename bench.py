@@ -97,6 +97,9 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
     args = ap.parse_args()
 
+    if os.environ.get('VCA_BENCH_HANG_TRACE'):      # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['VCA_BENCH_HANG_TRACE']), exit=True)
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -164,7 +167,9 @@ def main():
             'metric': 'lip-video frames/sec (G+D fwd+bwd step) @ B32xT75x96x96 per GPU',
             'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic', 'launch': 'hip-graph' if graphed is not None else 'eager',
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'launch': ('eager' if graphed is None else
+                       '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph'),
             'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                    'weights' % args.batch, 'global_batch': args.batch * world,
                        'parallelism': 'dp%d' % world},

@@ -125,7 +125,8 @@ def test_step_matches_reference(variant, prec):
 
 @gpu
 def test_graph_replay_matches_eager():
-    """A step captured into a HIP graph and replayed gives the same losses as issuing the kernels from Python
+    """A step captured into one HIP graph, or into the three per-phase graphs the data-parallel path replays around
+    its gradient all-reduces, gives the same losses as issuing the kernels from Python
     (fp32 atomics make any two runs differ in the last bits and the sign-like first Adam steps amplify that: two
     eager runs of this case differ by ~0.5 % in gen_loss after 4 steps, so the bound here is 3 %)."""
     from vcagan_amd import ops, train_step
@@ -133,7 +134,7 @@ def test_graph_replay_matches_eager():
     B, T, H = 2, 20, 112
     b = _cuda_batch(fixtures.make_batch(B, T, H, 5, [20, 13]))
     out = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'graph', 'segmented'):
         m = _models(300, True)
         opts = train_step.build_optimizers(m)
         step = train_step.GanStep(m, opts, 'grid')
@@ -141,11 +142,14 @@ def test_graph_replay_matches_eager():
             for _ in range(4):
                 res = step(b['mel'], b['spec'], b['vid'], b['vid_len'], noise=b['noise'])
         else:
-            gs = train_step.GraphedStep(step, b['mel'], b['spec'], b['vid'], b['vid_len'], b['noise'], warmup=2)
+            gs = train_step.GraphedStep(step, b['mel'], b['spec'], b['vid'], b['vid_len'], b['noise'], warmup=2,
+                                        segmented=(mode == 'segmented'))
+            assert len(gs.graphs) == (3 if mode == 'segmented' else 1)
             for _ in range(2):
                 res = gs(b['mel'], b['spec'], b['vid'], None, b['noise'])
         torch.cuda.synchronize()
         out[mode] = {k: float(res[k]) for k in ('dis_loss', 'gen_loss', 'recon_loss', 'sync_loss')}
         assert opts[0].t_dev.item() == 4 and opts[1].t_dev.item() == 4
-    for k in out['eager']:
-        assert abs(out['eager'][k] - out['graph'][k]) <= 3e-2 * abs(out['eager'][k]), (k, out)
+    for mode in ('graph', 'segmented'):
+        for k in out['eager']:
+            assert abs(out['eager'][k] - out[mode][k]) <= 3e-2 * abs(out['eager'][k]), (mode, k, out)

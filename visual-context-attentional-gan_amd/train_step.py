@@ -70,6 +70,16 @@ class GanStep:
 
     def __call__(self, mel, spec, vid, vid_len, noise=None):
         """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths."""
+        self.d_phase(mel, spec, vid, vid_len, noise)
+        self.d_exchange.reduce()
+        self.g_phase()
+        self.g_exchange.reduce()
+        return self.finish()
+
+    # The step is three device-only phases separated by the two gradient exchanges, so that a caller can replay
+    # each phase as one HIP graph and keep the collectives outside the graphs.
+    def d_phase(self, mel, spec, vid, vid_len, noise=None):
+        """Forward of the generator side, discriminator losses and their backward (train.py:170-210)."""
         m = self.m
         self._zero(G_NAMES)
         mel1 = F.interpolate(mel, scale_factor=0.25, mode='bilinear', align_corners=False)
@@ -81,7 +91,6 @@ class GanStep:
         sd = sent.detach()
         dis = (m['dis1'], m['dis2'], m['dis3'])
 
-        # ---- discriminator phase (train.py:182-211)
         real_lo = [d(r, sd, T) for d, r in zip(dis, reals)]
         # The sync loss is the only D-phase term that reaches v_front (train.py:186,210 "accumulate v_front grad").
         # Back-propagation is linear in the incoming gradient, so instead of running v_front's backward twice (once
@@ -101,10 +110,17 @@ class GanStep:
         dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
         self._zero(D_NAMES)
         dis_loss.backward()
-        self.d_exchange.reduce()
-        self.d_opt.step()
+        self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
+                        tgt=[r.detach() for r in reals], dis_loss=dis_loss.detach(), sync_loss=sync_loss.detach(),
+                        grad_p=torch.stack([x.detach() for x in grad_p]))
 
-        # ---- generator phase (train.py:215-237)
+    def g_phase(self):
+        """d_optimizer.step(), then the generator losses and their backward (train.py:211-235)."""
+        m, st = self.m, self._st
+        self.d_opt.step()
+        g1, g2, g3 = st['g']
+        phon, sd, T = st['phon'], st['sd'], st['T']
+        dis = (m['dis1'], m['dis2'], m['dis3'])
         # The reference also back-propagates gen_loss into the discriminators' weights and throws those gradients
         # away (d_optimizer.zero_grad() precedes their next use, train.py:209); here they are simply not computed.
         d_params = [p for n in D_NAMES for p in m[n].parameters()]
@@ -114,38 +130,45 @@ class GanStep:
         gen_lo = [d(g, sd, T) for d, g in zip(dis, (g1, g2, g3))]
         g_sync = m['s_dis'](phon.detach(), g3, gen=True).mean()
         g_adv = (sum(G.gan_loss(u, True) for u, _ in gen_lo) + sum(G.gan_loss(c, True) for _, c in gen_lo)) / 3
-        tgt = [r.detach() for r in reals]
+        tgt = st['tgt']
         if self.variant == 'grid':
             g_loss = g_adv + g_sync
             k = -_LOG_EPS / 2.0           # slope of the de-normalisation applied to both L1 arguments
-            recon = sum(ops.l1_mean(g, t, k) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, spec)
+            recon = sum(ops.l1_mean(g, t, k) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, st['spec'])
             gen_loss = g_loss + 50.0 * recon
         else:
             g_loss = g_adv
-            recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, spec)
+            recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, st['spec'])
             gen_loss = g_loss + 50.0 * recon + g_sync
         self._zero(D_NAMES + ('gen', 'post'))
-        torch.autograd.backward([gen_loss, phon], [None, phon_d.grad])
+        torch.autograd.backward([gen_loss, phon], [None, st['phon_d'].grad])
         for p in d_params:
             p.requires_grad_(True)
-        self.g_exchange.reduce()
+        self._st = dict(dis_loss=st['dis_loss'], gen_loss=gen_loss.detach(), sync_loss=st['sync_loss'],
+                        g_sync_loss=g_sync.detach(), recon_loss=recon.detach(), g_loss=g_loss.detach(),
+                        grad_p=st['grad_p'], g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+
+    def finish(self):
+        """g_optimizer.step() (train.py:236); returns the step's losses and outputs."""
         self.g_opt.step()
-        return dict(dis_loss=dis_loss.detach(), gen_loss=gen_loss.detach(), sync_loss=sync_loss.detach(),
-                    g_sync_loss=g_sync.detach(), recon_loss=recon.detach(), g_loss=g_loss.detach(),
-                    grad_p=torch.stack([x.detach() for x in grad_p]),
-                    g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+        out, self._st = self._st, None
+        return out
 
 
 class GraphedStep:
-    """A GanStep captured once into a HIP graph and replayed: one graph launch per training step instead of several
-    thousand kernel launches issued from Python.  Inputs are copied into static device buffers before each replay;
-    the returned tensors are the graph's static outputs (overwritten by the next call).  Shapes are fixed at capture."""
+    """A GanStep captured once into HIP graphs and replayed instead of several thousand kernel launches issued from
+    Python per training step.  A single process captures the whole step as one graph; with data parallelism (or
+    segmented=True) the three phases are three graphs sharing one memory pool, replayed in order with the two
+    gradient all-reduces issued between them on the same stream, so no collective is ever captured.  Inputs are
+    copied into static device buffers before each replay; the returned tensors are the graphs' static outputs
+    (overwritten by the next call).  Shapes are fixed at capture."""
 
-    def __init__(self, step, mel, spec, vid, vid_len, noise, warmup=2):
+    def __init__(self, step, mel, spec, vid, vid_len, noise, warmup=2, segmented=None):
         self.step = step
         dev = mel.device
         self.static = dict(mel=mel.clone(), spec=spec.clone(), vid=vid.clone(), noise=noise.clone(),
                            vid_len=torch.as_tensor([int(l) for l in vid_len], device=dev))
+        self.segmented = (step.d_exchange.world > 1) if segmented is None else bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -153,9 +176,24 @@ class GraphedStep:
                 self._run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._run()
+        s = self.static
+        if not self.segmented:
+            self.graphs = [torch.cuda.CUDAGraph()]
+            with torch.cuda.graph(self.graphs[0]):
+                self.out = self._run()
+        else:
+            # Other threads (the process group's watchdog) may touch the device while a phase is being captured.
+            mode = 'thread_local' if step.d_exchange.world > 1 else 'global'
+            pool = torch.cuda.graph_pool_handle()
+            self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
+                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], s['noise'])
+            step.d_exchange.reduce()         # keeps the ranks' collective sequences aligned; the data is not used
+            with torch.cuda.graph(self.graphs[1], pool=pool, capture_error_mode=mode):
+                step.g_phase()
+            step.g_exchange.reduce()
+            with torch.cuda.graph(self.graphs[2], pool=pool, capture_error_mode=mode):
+                self.out = step.finish()
         self.warmup_steps = warmup
 
     def _run(self):
@@ -169,5 +207,12 @@ class GraphedStep:
                 s[k].copy_(v, non_blocking=True)
         if vid_len is not None and not (torch.is_tensor(vid_len) and vid_len.data_ptr() == s['vid_len'].data_ptr()):
             s['vid_len'].copy_(torch.as_tensor([int(l) for l in vid_len]), non_blocking=True)
-        self.graph.replay()
+        if not self.segmented:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            self.step.d_exchange.reduce()
+            self.graphs[1].replay()
+            self.step.g_exchange.reduce()
+            self.graphs[2].replay()
         return self.out
