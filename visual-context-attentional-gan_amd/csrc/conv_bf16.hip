@@ -138,9 +138,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
     __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
     // ---- stage the halo of this 32-channel slice
-#ifdef EXP_NOHALO
-    if (chunk == chunk_beg)
-#endif
     for (int it = tid; it < npos_total * 2; it += 256) {
       const int pos = it >> 1, half = it & 1;
       const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
@@ -206,9 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int buf = tap & 1;
-#ifndef EXP_NOB
       if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk);
-#endif
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
       const int tapoff = kh * a.HW + kw;
       const unsigned char* bh_base = bbase + buf * BBUF;
@@ -241,10 +236,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
       }
-#ifndef EXP_NOB
       if (tap + 1 < a.ntaps) commit_b(buf ^ 1);
       __syncthreads();
-#endif
     }
   }
 
