@@ -559,6 +559,200 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight gradient for filters of at most 9 taps (3x3, 1x1, short 1-D): a workgroup of 4 waves owns a 64 x 64
+// (ci x co) tile of every tap; wave (h_ci, h_co) owns one 32 x 32 quadrant and keeps the accumulators of all taps
+// in registers.  Per patch of 128 output pixels the input halo [position][64 ci] and the output-gradient tile
+// [pixel][64 co] are staged once (as two 32-channel images each, in the layout of the kernel above) and serve
+// four times the MFMA work the 32 x 32 workgroup tile gets from the same staging; the output-gradient fragments
+// of half a patch stay in registers while the taps sweep it.
+// ------------------------------------------------------------------------------------------------
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAXT = 9;
+  const vca_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cih = wave >> 1, coh = wave & 1;
+  const int npos_total = a.NI * a.NPOS;
+  unsigned char* halo_hi = smem;                                   // [2 ci halves][position][32 ci]
+  unsigned char* halo_lo = halo_hi + 2 * npos_total * 64;
+  unsigned char* gy_hi = halo_lo + (NSPLIT == 3 ? 2 * npos_total * 64 : 0);   // [2 co halves][pixel][32 co]
+  unsigned char* gy_lo = gy_hi + 2 * BM * 64;
+
+  const int cot = blockIdx.x % a.co_tiles, cit = blockIdx.x / a.co_tiles;
+  const int ci_base = cit * 64, co_base = cot * 64;
+  const int He = d.Hin << d.ups, We = d.Win << d.ups;
+  const int tpix = a.TH * a.TW;
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int col = 16 * (g & 1) + 4 * p;
+  const int kq = 8 * (g >> 1) + q;
+  const int colchunk = col >> 3, colbyte = (col & 7) * 2;
+  int pk[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = (s >> 1) * 16 + kq + 4 * (s & 1);
+    const int img = k / tpix, rem = k - img * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    pk[s] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
+  }
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const unsigned char* my_hh = halo_hi + cih * npos_total * 64;
+  const unsigned char* my_hl = halo_lo + cih * npos_total * 64;
+  const unsigned char* my_gh = gy_hi + coh * BM * 64;
+  const unsigned char* my_gl = gy_lo + coh * BM * 64;
+
+  const int pt_beg = blockIdx.y * a.tiles_per_block;
+  const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
+  for (int pt = pt_beg; pt < pt_end; ++pt) {
+    const int sid0 = pt * a.NI;
+    __syncthreads();
+    // ---- input halo, channels ci_base .. ci_base+63: 4 threads per position, 16 channels each
+    for (int it = tid; it < npos_total * 4; it += 256) {
+      const int pos = it >> 2, qtr = it & 3;
+      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
+      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      int n, oy0, ox0;
+      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
+      const bool ok = sv && vy >= 0 && vx >= 0 && vy < He && vx < We;
+      vy >>= d.ups;
+      vx >>= d.ups;
+      const int ci0 = ci_base + qtr * 16;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = 0.f;
+      if (ok && ci0 < d.Cin) {
+        const float* src = a.x + ((size_t)(n * d.Hin + vy) * d.Win + vx) * d.Cin + ci0;
+        if (a.vecA && ci0 + 16 <= d.Cin) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const float4 t = *reinterpret_cast<const float4*>(src + 4 * qq);
+            v[4 * qq] = t.x; v[4 * qq + 1] = t.y; v[4 * qq + 2] = t.z; v[4 * qq + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (ci0 + j < d.Cin) v[j] = src[j];
+        }
+        if (a.in_scale || d.act) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ci = ci0 + j;
+            if (ci < d.Cin) {
+              float z = v[j];
+              if (a.in_scale) z = z * a.in_scale[ci] + a.in_shift[ci];
+              if (d.act) z = vca_act(z, d.act, d.act == VCA_ACT_PRELU ? a.in_alpha[ci] : d.slope);
+              v[j] = z;
+            }
+          }
+        }
+      }
+      const int sw = (pos >> 2) & 3, sub = qtr & 1;
+      const int base = (qtr >> 1) * npos_total * 64 + pos * 64;
+      uint4 h0, l0, h1, l1;
+      split8(v, h0, l0);
+      split8(v + 8, h1, l1);
+      *reinterpret_cast<uint4*>(halo_hi + base + (((2 * sub) ^ sw) << 4)) = h0;
+      *reinterpret_cast<uint4*>(halo_hi + base + (((2 * sub + 1) ^ sw) << 4)) = h1;
+      if (NSPLIT == 3) {
+        *reinterpret_cast<uint4*>(halo_lo + base + (((2 * sub) ^ sw) << 4)) = l0;
+        *reinterpret_cast<uint4*>(halo_lo + base + (((2 * sub + 1) ^ sw) << 4)) = l1;
+      }
+    }
+    // ---- output-gradient tile [128 pixels][64 co]: 8 threads per pixel, 8 channels each
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const int it = tid + rep * 256;
+      const int m = it >> 3, oc = it & 7;
+      const int img = m / tpix, rem = m - img * tpix;
+      const int ty = rem / a.TW, tx = rem - ty * a.TW;
+      int n, oy0, ox0;
+      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const int c0 = co_base + oc * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (img < a.NI && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+        const float* src = a.gy + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.Cout + c0;
+        if (a.vecB && c0 + 8 <= d.Cout) {
+          const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
+          v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j < d.Cout) v[j] = src[j];
+        }
+      }
+      const int sw = (m >> 2) & 3, qt = oc & 3;
+      const int base = (oc >> 2) * BM * 64 + m * 64 + ((qt ^ sw) << 4);
+      uint4 h0, l0;
+      split8(v, h0, l0);
+      *reinterpret_cast<uint4*>(gy_hi + base) = h0;
+      if (NSPLIT == 3) *reinterpret_cast<uint4*>(gy_lo + base) = l0;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x8 bh[4], bl[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k0 = (hf * 4 + kk) * 16 + kq, k1 = k0 + 4;
+        const int o0 = k0 * 64 + ((colchunk ^ ((k0 >> 2) & 3)) << 4) + colbyte;
+        const int o1 = k1 * 64 + ((colchunk ^ ((k1 >> 2) & 3)) << 4) + colbyte;
+        bh[kk] = tr_read8(my_gh + o0, my_gh + o1);
+        if (NSPLIT == 3) bl[kk] = tr_read8(my_gl + o0, my_gl + o1);
+      }
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < a.ntaps) {
+          const int kh = t / d.KW, kw = t - kh * d.KW;
+          int tapoff = kh * a.HW + kw;
+          // keeps the 72 per-(tap, slice) LDS addresses from being hoisted out of the patch loop into registers
+          asm volatile("" : "+s"(tapoff));
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int ks = hf * 4 + kk;
+            const int p0 = pk[2 * ks] + tapoff, p1 = pk[2 * ks + 1] + tapoff;
+            const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
+            const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
+            const bf16x8 ah = tr_read8(my_hh + o0, my_hh + o1);
+            if (NSPLIT == 3) {
+              const bf16x8 al = tr_read8(my_hl + o0, my_hl + o1);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- accumulate into dW: D[row = ci][col = co]
+  const int lr = lane & 31, lh = lane >> 5;
+  const int co = co_base + coh * 32 + lr;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    if (t < a.ntaps && co < d.Cout) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci_base + cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < d.Cin) atomicAdd(a.dw + ((size_t)t * d.Cin + ci) * a.Cout4 + co, acc[t][r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing: fp32 [Cout][Cin][taps] -> bf16 [tap][chunk][npad][hi 32 | lo 32]
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, int N, int K, int npad, int nchunk,
@@ -590,12 +784,14 @@ struct TileChoice {
 
 // Patch shape maximising the fraction of the 128 GEMM rows that are real output pixels, subject to the halo
 // fitting in LDS.  Cached per geometry.
-TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Cout) {
+TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Cout, int maxpos = MAXPOS,
+                       double stage_cost = 6.0) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, TileChoice> cache;
   const unsigned long long key = ((unsigned long long)N << 44) ^ ((unsigned long long)OH << 32) ^
                                  ((unsigned long long)OW << 20) ^ (KH << 12) ^ (KW << 4) ^ stride ^
-                                 ((unsigned long long)(Cout > 96 ? 3 : (Cout > 32 ? 2 : 1)) << 58);
+                                 ((unsigned long long)(Cout > 96 ? 3 : (Cout > 32 ? 2 : 1)) << 58) ^
+                                 ((unsigned long long)maxpos << 8) ^ ((unsigned long long)(stage_cost * 4) << 24);
   {
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find(key);
@@ -609,13 +805,13 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Co
   for (int th = 1; th <= OH && th <= BM; ++th) {
     for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
       const int hh = (th - 1) * stride + KH, hw = (tw - 1) * stride + KW;
-      if (hh * hw > MAXPOS) continue;
+      if (hh * hw > maxpos) continue;
       const long long nsub = (long long)N * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
       int ni = BM / (th * tw);
       if (ni > nsub) ni = (int)nsub;
-      while (ni > 1 && ni * hh * hw > MAXPOS) --ni;
+      while (ni > 1 && ni * hh * hw > maxpos) --ni;
       const long long groups = (nsub + ni - 1) / ni;
-      double cost = (double)groups * (mfma + 6.0 * ni * hh * hw);
+      double cost = (double)groups * (mfma + stage_cost * ni * hh * hw);
       cost *= 1.0 + 0.02 / tw;   // tie-break: wider patches (longer contiguous runs, fewer LDS bank conflicts)
       if (cost < best_cost) {
         best_cost = cost;
@@ -673,7 +869,15 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.x = x; a.gy = gy; a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.dw = dwpack;
   a.Cout4 = (d->Cout + 3) & ~3;
   a.ntaps = d->KH * d->KW;
-  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
+  // at most 9 taps: 64 x 64 tiles, one quadrant per wave (halo of at most 192 positions keeps two workgroups
+  // per CU; a patch that needs more, e.g. many 3x3 maps, may take the CU's LDS alone if that wastes fewer MFMAs)
+  const bool quad = a.ntaps <= 9;
+  TileChoice t;
+  if (quad) {
+    t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, 128, 192, 12.0);
+  } else {
+    t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
+  }
   a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
   a.HH = (t.TH - 1) * d->stride + d->KH;
   a.HW = (t.TW - 1) * d->stride + d->KW;
@@ -682,26 +886,29 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.tiles_y = (d->OH + t.TH - 1) / t.TH;
   a.nsub = d->N * a.tiles_x * a.tiles_y;
   a.ntiles = (a.nsub + t.NI - 1) / t.NI;
-  a.co_tiles = (d->Cout + 31) / 32;
-  const int ci_tiles = (d->Cin + 31) / 32;
+  const int tile_c = quad ? 64 : 32;
+  a.co_tiles = (d->Cout + tile_c - 1) / tile_c;
+  const int ci_tiles = (d->Cin + tile_c - 1) / tile_c;
   const int out_tiles = a.co_tiles * ci_tiles;
-  int split = (2048 + out_tiles - 1) / out_tiles;
-  if (split > 256) split = 256;          // bounds the atomic adds that land on one dW tile
+  int split = ((quad ? 1024 : 2048) + out_tiles - 1) / out_tiles;
+  if (split > (quad ? 512 : 256)) split = quad ? 512 : 256;   // bounds the atomic adds that land on one dW tile
   if (split > a.ntiles) split = a.ntiles;
   if (split < 1) split = 1;
   a.tiles_per_block = (a.ntiles + split - 1) / split;
   split = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
   a.vecB = (d->Cout % 4 == 0) ? 1 : 0;
-  const size_t lds = ((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1);
+  const size_t lds = ((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[4] = {reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
+    const void* ks[6] = {reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
                          reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, false>),
                          reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, true>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>)};
-    for (int i = 0; i < 4; ++i) {
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<3>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<1>)};
+    for (int i = 0; i < 6; ++i) {
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
     }
@@ -710,7 +917,10 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   // many taps: whole taps per wave (output-gradient fragments stay in registers); few taps: balanced unit runs
   const bool rr = a.ntaps > 16;
   const dim3 grid(out_tiles, split), blk(512);
-  if (nsplit == 3) {
+  if (quad) {
+    if (nsplit == 3) hipLaunchKernelGGL((conv_bf16_wgrad_quad_kernel<3>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_bf16_wgrad_quad_kernel<1>), grid, dim3(256), lds, s, a);
+  } else if (nsplit == 3) {
     if (rr) hipLaunchKernelGGL((conv_bf16_wgrad_kernel<3, true>), grid, blk, lds, s, a);
     else hipLaunchKernelGGL((conv_bf16_wgrad_kernel<3, false>), grid, blk, lds, s, a);
   } else {
