@@ -75,6 +75,11 @@ int vca_conv_wgrad_f32(const vca_conv_desc* d, const float* x, const float* gy,
  *   mode 2: unpack-accumulate a weight gradient: w[co][ci][t] = beta*w[co][ci][t] + wpack[t][ci][co] */
 int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const float* src, float* dst, float beta,
                         void* stream);
+/* Mode 2 of vca_pack_weight_f32 with coalesced traffic on both sides; with clear != 0 the workspace dwpack is
+ * zeroed behind the read, so a workspace that is only ever filled by vca_conv_wgrad_* and drained by this call
+ * stays zeroed between uses (the gradient that autograd accumulates into nn.Parameter.grad, train.py:209,235). */
+int vca_unpack_wgrad_f32(int Cout, int Cin, int taps, float* dwpack, float* w_grad, float beta, int clear,
+                         void* stream);
 
 /* Split-bf16 variant of vca_conv_fwd_f32 on v_mfma_f32_32x32x16_bf16 (2-D maps, Cin > 1; used for the
  * forward pass and, with the input-gradient descriptor, for the input gradient).  nsplit = 3: every fp32

@@ -778,6 +778,58 @@ __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, i
   dst[row + 32 + j] = l;
 }
 
+// Same packing for filters of at most 32 taps with coalesced traffic on both sides: a workgroup stages the
+// 32 k x 8 n x taps source values of one (channel slice, 8 output rows) group in LDS (the source is contiguous
+// over (k, tap) for a fixed n in mode 0 and over (n, tap) for a fixed k in mode 1) and writes whole 128-byte rows.
+__global__ __launch_bounds__(256) void pack_weight_bf16_tiled_kernel(int mode, int Cin, int taps, int N, int K,
+                                                                     int npad, int nchunk,
+                                                                     const float* __restrict__ src,
+                                                                     __bf16* __restrict__ dst) {
+  extern __shared__ float tl[];   // [8 n][32 k][taps]
+  const int chunk = blockIdx.x, n0 = blockIdx.y * 8, k0 = chunk * 32;
+  const int tid = threadIdx.x;
+  const int per = 32 * taps, total = 8 * per;
+  if (mode == 0) {
+    const int rmax = min(K - k0, 32) * taps;          // entries of this slice that exist in the source
+    for (int r = tid; r < per; r += 256) {
+      float v[8];
+#pragma unroll
+      for (int nl = 0; nl < 8; ++nl)
+        v[nl] = (n0 + nl < N && r < rmax) ? src[((size_t)(n0 + nl) * Cin + k0) * taps + r] : 0.f;
+#pragma unroll
+      for (int nl = 0; nl < 8; ++nl) tl[nl * per + r] = v[nl];
+    }
+  } else {
+    const int nl = tid / taps, tt = tid - nl * taps;  // 8*taps <= 256: one source element per thread and k
+    const int n = n0 + nl;
+    if (nl < 8) {
+      float v[32];
+#pragma unroll
+      for (int kl = 0; kl < 32; ++kl) {     // all 32 loads in flight before the first LDS write
+        const int k = k0 + kl;
+        v[kl] = (n < N && k < K) ? src[((size_t)k * Cin + n) * taps + tt] : 0.f;
+      }
+#pragma unroll
+      for (int kl = 0; kl < 32; ++kl) tl[(nl * 32 + kl) * taps + (taps - 1 - tt)] = v[kl];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < taps * 32; i += 256) {       // (tap, n, quarter row): 8 k -> one 16-byte hi and lo store
+    const int jq = i & 3, nl = (i >> 2) & 7, t = i >> 5;
+    const int n = n0 + nl;
+    if (n < npad) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = tl[(nl * 32 + jq * 8 + u) * taps + t];
+      uint4 h, l;
+      split8(v, h, l);
+      unsigned char* row = reinterpret_cast<unsigned char*>(dst) + ((size_t)(t * nchunk + chunk) * npad + n) * 128;
+      *reinterpret_cast<uint4*>(row + jq * 16) = h;
+      *reinterpret_cast<uint4*>(row + 64 + jq * 16) = l;
+    }
+  }
+}
+
 struct TileChoice {
   int NI, TH, TW;
 };
@@ -940,6 +992,12 @@ extern "C" int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const
   VCA_CHECK_ARG((mode == 0 || mode == 1) && Cout > 0 && Cin > 0 && taps > 0 && src && dst);
   const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
   const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
+  if (taps <= 32) {
+    const dim3 grid(nchunk, npad / 8);
+    hipLaunchKernelGGL(pack_weight_bf16_tiled_kernel, grid, dim3(256), (size_t)8 * 32 * taps * sizeof(float),
+                       (hipStream_t)stream, mode, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));
+    return vca_launch_status();
+  }
   const size_t total = (size_t)taps * nchunk * npad * 32;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      mode, Cout, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));

@@ -483,6 +483,46 @@ __global__ void pack_weight_kernel(int mode, int Cout, int Cin, int taps, const 
   }
 }
 
+// dst[co][ci][t] = beta*dst + src[t][ci][co4], and src is cleared behind the read: the weight-gradient kernels
+// accumulate into src with atomics, so a workspace that is always handed back zeroed never needs a fill launch.
+// A workgroup transposes 32 co x 64 (ci,t) entries through LDS so both the reads and the writes are coalesced.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(int Cout, int Cin, int taps, float* __restrict__ src,
+                                                           float* __restrict__ dst, float beta, int clear) {
+  __shared__ float tile[64][33];
+  const int Cout4 = (Cout + 3) & ~3;
+  const int E = Cin * taps;
+  const int e0 = blockIdx.x * 64, co0 = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  {
+    const int cl = tid & 31, co = co0 + cl;
+    int el = tid >> 5;
+    int ci = (e0 + el) / taps, t = (e0 + el) - ci * taps;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass, el += 8) {
+      float v = 0.f;
+      if (e0 + el < E && co < Cout4) {
+        float* ps = src + ((size_t)t * Cin + ci) * Cout4 + co;
+        v = *ps;
+        if (clear) *ps = 0.f;
+      }
+      tile[el][cl] = v;
+      t += 8;
+      while (t >= taps) { t -= taps; ++ci; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int cl = pass * 4 + (tid >> 6), el = tid & 63;
+    const int e = e0 + el, co = co0 + cl;
+    if (e < E && co < Cout) {
+      float* pd = dst + (size_t)co * E + e;
+      const float v = tile[el][cl];
+      *pd = beta == 0.f ? v : beta * *pd + v;
+    }
+  }
+}
+
 bool desc_ok(const vca_conv_desc* d) {
   return d && d->N > 0 && d->D > 0 && d->Hin > 0 && d->Win > 0 && d->Cin > 0 && d->OD > 0 && d->OH > 0 &&
          d->OW > 0 && d->Cout > 0 && d->KD > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad_h >= 0 && d->pad_w >= 0 &&
@@ -594,5 +634,16 @@ extern "C" int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const 
   const int thr = 256;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + thr - 1) / thr)), dim3(thr), 0,
                      (hipStream_t)stream, mode, Cout, Cin, taps, src, dst, beta);
+  return vca_launch_status();
+}
+
+extern "C" int vca_unpack_wgrad_f32(int Cout, int Cin, int taps, float* dwpack, float* dst, float beta, int clear,
+                                    void* stream) {
+  VCA_CHECK_ARG(Cout > 0 && Cin > 0 && taps > 0 && dwpack && dst);
+  const long long E = (long long)Cin * taps;
+  VCA_CHECK_ARG(E < (1ll << 31));
+  const dim3 grid((unsigned)((E + 63) / 64), (unsigned)((((Cout + 3) & ~3) + 31) / 32));
+  hipLaunchKernelGGL(unpack_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, Cout, Cin, taps, dwpack, dst, beta,
+                     clear);
   return vca_launch_status();
 }

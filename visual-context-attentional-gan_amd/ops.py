@@ -158,9 +158,40 @@ def _conv_dgrad_raw(gy, w, cfg):
     return gx.view(cfg.xshape)
 
 
-def _conv_wgrad_raw(x, gy, cfg):
+_wgrad_ws = {}          # (device, shape) -> [taps][Cin][Cout4] workspace, zero whenever no kernel is using it; shared by
+                        # every layer of that shape, so weight gradients must be issued on one stream at a time
+_direct_grad = [False]  # set by direct_param_grad()
+
+
+class direct_param_grad:
+    """While active, the weight gradient of a leaf parameter whose .grad is already allocated (the flat gradient
+    buffers of flatten_module) is accumulated straight into it by the unpack kernel instead of being returned to
+    autograd, which would materialise it and add it with one more kernel per parameter."""
+
+    def __enter__(self):
+        self.prev = _direct_grad[0]
+        _direct_grad[0] = True
+
+    def __exit__(self, *exc):
+        _direct_grad[0] = self.prev
+
+
+def _grad_sink(w):
+    if (_direct_grad[0] and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.grad is not None
+            and w.grad.is_contiguous()):
+        return w.grad
+    return None
+
+
+def _conv_wgrad_raw(x, gy, cfg, sink=None):
+    """Weight gradient in the parameter's layout; with `sink` (a contiguous tensor of that layout) it is added to
+    sink and None is returned."""
     cout, cin, taps = cfg.cout, cfg.cin, cfg.kd * cfg.kh * cfg.kw
-    dwp = torch.zeros((taps, cin, (cout + 3) // 4 * 4), device=x.device, dtype=torch.float32)
+    shape = (taps, cin, (cout + 3) // 4 * 4)
+    key = (x.device, shape)
+    dwp = _wgrad_ws.get(key)
+    if dwp is None:
+        dwp = _wgrad_ws[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
     ns = _nsplit(True)
     if ns and cin > 1 and cfg.kd == 1 and taps <= 32:
         check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
@@ -168,9 +199,11 @@ def _conv_wgrad_raw(x, gy, cfg):
     else:
         check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
               'conv_wgrad')
-    gw = torch.empty(cfg.pshape, device=x.device, dtype=torch.float32)
-    check(_lib.lib().vca_pack_weight_f32(2, cout, cin, taps, ptr(dwp), ptr(gw), 0.0, stream()), 'unpack_wgrad')
-    return gw
+    gw = sink if sink is not None else torch.empty(cfg.pshape, device=x.device, dtype=torch.float32)
+    # the unpack kernel zeroes the workspace behind its reads
+    check(_lib.lib().vca_unpack_wgrad_f32(cout, cin, taps, ptr(dwp), ptr(gw), 1.0 if sink is not None else 0.0, 1,
+                                          stream()), 'unpack_wgrad')
+    return None if sink is not None else gw
 
 
 def _c(t):
@@ -198,7 +231,7 @@ class ConvStatsFn(torch.autograd.Function):
         cfg = ctx.cfg
         gy = _c(gy)
         gx = _conv_dgrad_raw(gy, w, cfg) if ctx.needs_input_grad[0] else None
-        gw = _conv_wgrad_raw(_c(x), gy, cfg) if ctx.needs_input_grad[1] else None
+        gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
         gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
@@ -218,7 +251,10 @@ class ConvFn(torch.autograd.Function):
         gy = _c(gy)
         _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, w, cfg) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(x, gy, cfg) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            sink = _grad_sink(w)
+            gw = ConvWgradFn.apply(x, gy, cfg) if sink is None else _conv_wgrad_raw(_c(x), gy, cfg, sink)
         _exact_bwd[0] = False
         gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
@@ -238,7 +274,10 @@ class ConvDgradFn(torch.autograd.Function):
         ggx = _c(ggx)
         _exact_bwd[0] = torch.is_grad_enabled()
         ggy = ConvFn.apply(ggx, w, None, cfg) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(ggx, gy, cfg) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            sink = _grad_sink(w)
+            gw = ConvWgradFn.apply(ggx, gy, cfg) if sink is None else _conv_wgrad_raw(ggx, _c(gy), cfg, sink)
         _exact_bwd[0] = False
         return ggy, gw, None
 
@@ -339,7 +378,7 @@ class StemConvFn(torch.autograd.Function):
     @once
     def backward(ctx, gy, _gstats):
         x, w = ctx.saved_tensors
-        gw = _conv_wgrad_raw(x, _c(gy), ctx.cfg) if ctx.needs_input_grad[1] else None
+        gw = _conv_wgrad_raw(x, _c(gy), ctx.cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
         return None, gw, None
 
 

@@ -109,7 +109,8 @@ class GanStep:
                      + sum(G.gan_loss(c, False) for _, c in fake_lo)) / 3
         dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
         self._zero(D_NAMES)
-        dis_loss.backward()
+        with ops.direct_param_grad():
+            dis_loss.backward()
         self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
                         tgt=[r.detach() for r in reals], dis_loss=dis_loss.detach(), sync_loss=sync_loss.detach(),
                         grad_p=torch.stack([x.detach() for x in grad_p]))
@@ -141,7 +142,8 @@ class GanStep:
             recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, st['spec'])
             gen_loss = g_loss + 50.0 * recon + g_sync
         self._zero(D_NAMES + ('gen', 'post'))
-        torch.autograd.backward([gen_loss, phon], [None, st['phon_d'].grad])
+        with ops.direct_param_grad():
+            torch.autograd.backward([gen_loss, phon], [None, st['phon_d'].grad])
         for p in d_params:
             p.requires_grad_(True)
         self._st = dict(dis_loss=st['dis_loss'], gen_loss=gen_loss.detach(), sync_loss=st['sync_loss'],
