@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   constexpr int BROW = (NSPLIT == 3) ? 128 : 64;  // bytes of one packed weight row that are used
   constexpr int BBUF = BN * BROW;                 // bytes of one weight LDS buffer
-  constexpr int NBP = (BN * (BROW / 16) + 255) / 256;
 
   const vca_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,32 +106,31 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 rbw[NBP];
-  auto issue_b = [&](int tap, int chunk) {
-    const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad + n0) * 128;
+  // Weight tiles go from global memory straight into LDS (global_load_lds_dwordx4: no registers, no ds_write).
+  // One wave-instruction fills 1 KiB = 16 rows x 64 B of the hi or lo image in lane order, so the XOR swizzle of
+  // the image is applied to the per-lane SOURCE address: lane l -> row 16*piece + l/4, slot l%4 holds source
+  // chunk (l%4) ^ ((row>>2)&3).
+  constexpr int NPIECE = BN * BROW / 1024;            // 16 (BN=128, split) ... 2 (BN=32, single)
+  constexpr int PPW = (NPIECE + 3) / 4;               // pieces per wave
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_b = [&](int tap, int chunk, int buf) {
+    const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad) * 128;
 #pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-      const int q = tid + i * 256;
-      rbw[i] = make_uint4(0, 0, 0, 0);
-      if (q < BN * (BROW / 16)) {
-        const int row = q / (BROW / 16), c = q - row * (BROW / 16);
-        if (n0 + row < a.npad) rbw[i] = *reinterpret_cast<const uint4*>(src + row * 128 + c * 16);
+    for (int i = 0; i < PPW; ++i) {
+      const int pi = wave_u * PPW + i;
+      if (pi < NPIECE) {
+        const int part = pi / (BN / 16), pr = pi - part * (BN / 16);
+        const int row = pr * 16 + (lane >> 2), slot = lane & 3;
+        const int grow = min(n0 + row, a.npad - 1);    // rows past the packed matrix feed columns that are never stored
+        const unsigned char* g = src + (size_t)grow * 128 + part * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+        unsigned char* l = bbase + buf * BBUF + part * (BN * 64) + pr * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
     }
   };
-  auto commit_b = [&](int buf) {
-    unsigned char* dst = bbase + buf * BBUF;
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-      const int q = tid + i * 256;
-      if (q < BN * (BROW / 16)) {
-        const int row = q / (BROW / 16), c = q - row * (BROW / 16);
-        const int part = c >> 2, cc = c & 3;  // part 0 = hi image, 1 = lo image
-        *reinterpret_cast<uint4*>(dst + part * (BN * 64) + row * 64 + ((cc ^ ((row >> 2) & 3)) << 4)) = rbw[i];
-      }
-    }
-  };
-
+  // the tile requested at the start of a tap must have landed before the barrier that ends the tap
+  auto wait_b = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
   const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
   for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
@@ -197,13 +195,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
         *reinterpret_cast<uint4*>(pl + (((2 * half + 1) ^ sw) << 4)) = l1;
       }
     }
-    issue_b(0, chunk);
-    commit_b(0);
+    issue_b(0, chunk, 0);
+    wait_b();
     __syncthreads();
 
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int buf = tap & 1;
-      if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk);
+      if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk, buf ^ 1);
       const int kh = tap / d.KW, kw = tap - kh * d.KW;
       const int tapoff = kh * a.HW + kw;
       const unsigned char* bh_base = bbase + buf * BBUF;
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
       }
-      if (tap + 1 < a.ntaps) commit_b(buf ^ 1);
+      wait_b();
       __syncthreads();
     }
   }
