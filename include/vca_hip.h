@@ -195,6 +195,19 @@ int vca_softplus_bwd_f32(int n, const float* x, float sign, float scale, const f
 int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, float* out, void* stream);
 int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
                    void* stream);
+/* Loss heads of sync_Discriminator.forward (generator.py:347-361) on the embeddings v, a [B][T][C] (T <= 160).
+ * nce (gen=False, :352-361): loss[b] = -1/2 mean_i (log_softmax(S,2)_ii + log_softmax(S,1)_ii) with
+ * S = normalize(v) normalize(a)^T / temp; S [B][T][T] and stats [B][4][T] (1/|v_i|, 1/|a_i|, row and column
+ * log-sum-exp) are kept for the backward call, which writes dv and/or da (either may be NULL) for the incoming
+ * gradient gloss[B].  cos (gen=True, :348-350): loss[b] = 5 - mean_t |cos(v_t, a_t)|, cosv [B][T] kept. */
+int vca_sync_nce_fwd_f32(int B, int T, int C, const float* v, const float* a, float temp, float* S, float* stats,
+                         float* loss, void* stream);
+int vca_sync_nce_bwd_f32(int B, int T, int C, const float* v, const float* a, const float* S, const float* stats,
+                         const float* gloss, float temp, float* dv, float* da, void* stream);
+int vca_sync_cos_fwd_f32(int B, int T, int C, const float* v, const float* a, float* cosv, float* loss, void* stream);
+int vca_sync_cos_bwd_f32(int B, int T, int C, const float* v, const float* a, const float* cosv, const float* gloss,
+                         float* dv, float* da, void* stream);
+
 /* torch.optim.Adam step (coupled L2 weight decay; amsgrad when vmax != NULL) over a flat buffer, n % 4 == 0
  * (train.py:82-83,211,237). `step` is the 1-based step count; when step_dev != NULL the count is read from that
  * device word instead (so the launch can be replayed from a captured HIP graph). */

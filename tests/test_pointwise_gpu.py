@@ -210,3 +210,39 @@ def test_attention_core(B, Tq, S, lens):
     out.backward(gy.cuda())
     assert rel_err(out, out_r) < 1e-5
     assert rel_err(qd.grad, qr.grad) < 2e-5 and rel_err(kd.grad, kr.grad) < 2e-5 and rel_err(vd.grad, vr.grad) < 2e-5
+
+
+@gpu
+@pytest.mark.parametrize('B,T,C,temp', [(3, 20, 512, 1.0), (2, 75, 512, 0.5), (2, 150, 96, 2.0)])
+def test_sync_loss_heads(B, T, C, temp):
+    """vca_sync_nce_* / vca_sync_cos_* vs the torch operators of generator.py:347-361 (fp32, 2e-5 relative)."""
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    v0 = torch.randn(B, T, C, generator=g)
+    a0 = torch.randn(B, T, C, generator=g) + 0.3 * v0     # correlated, so the diagonal stands out
+    w = torch.randn(B, generator=g)
+
+    def ref(gen):
+        v, a = v0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        if gen:
+            loss = 5.0 - F.cosine_similarity(v, a, 2).abs().mean(1)
+        else:
+            sim = torch.bmm(F.normalize(v, dim=2), F.normalize(a, dim=2).transpose(1, 2)) / temp
+            d_va = torch.diagonal(F.log_softmax(sim, 2), dim1=-2, dim2=-1).mean(1)
+            d_av = torch.diagonal(F.log_softmax(sim, 1), dim1=-2, dim2=-1).mean(1)
+            loss = -0.5 * (d_va + d_av)
+        (loss * w).sum().backward()
+        return loss, v.grad, a.grad
+
+    for gen in (False, True):
+        rl, rv, ra = ref(gen)
+        v, a = v0.cuda().requires_grad_(True), a0.cuda().requires_grad_(True)
+        loss = ops.sync_loss(v, a, temp, gen)
+        (loss * w.cuda()).sum().backward()
+        assert rel_err(loss, rl) < 2e-5, (gen, rel_err(loss, rl))
+        assert rel_err(v.grad, rv) < 5e-5, (gen, rel_err(v.grad, rv))
+        assert rel_err(a.grad, ra) < 5e-5, (gen, rel_err(a.grad, ra))
+    # only the audio side needs a gradient in the generator phase (train.py:221: v_feat is detached)
+    a = a0.cuda().requires_grad_(True)
+    ops.sync_loss(v0.cuda(), a, temp, True).sum().backward()
+    assert a.grad is not None and torch.isfinite(a.grad).all()

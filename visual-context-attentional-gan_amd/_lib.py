@@ -12,7 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
-SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip')
+SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
+           'sync_loss.hip')
 
 
 def build(force=False, verbose=False):
@@ -69,6 +70,10 @@ _SIGS = {
     'vca_softplus_bwd_f32': ([_I, _P, _F, _F, _P, _P, _P], _I),
     'vca_l1_sum_f32': ([_LL, _P, _P, _F, _P, _P], _I),
     'vca_l1_bwd_f32': ([_LL, _P, _P, _F, _P, _P, _P], _I),
+    'vca_sync_nce_fwd_f32': ([_I, _I, _I, _P, _P, _F, _P, _P, _P, _P], _I),
+    'vca_sync_nce_bwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P], _I),
+    'vca_sync_cos_fwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P], _I),
+    'vca_sync_cos_bwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 

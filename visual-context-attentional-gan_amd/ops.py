@@ -894,15 +894,66 @@ def masked_attention(q, k, v, lens, scale):
     return AttnCoreFn.apply(q, k, v, lens, float(scale))
 
 
+class SyncNceFn(torch.autograd.Function):
+    """Symmetric InfoNCE over the time steps of each sample (generator.py:352-361)."""
+
+    @staticmethod
+    def forward(ctx, v, a, temp):
+        v, a = _c(v), _c(a)
+        B, T, C = v.shape
+        S = torch.empty((B, T, T), device=v.device, dtype=torch.float32)
+        stats = torch.empty((B, 4, T), device=v.device, dtype=torch.float32)
+        loss = torch.empty((B,), device=v.device, dtype=torch.float32)
+        check(_lib.lib().vca_sync_nce_fwd_f32(B, T, C, ptr(v), ptr(a), float(temp), ptr(S), ptr(stats), ptr(loss),
+                                              stream()), 'sync_nce_fwd')
+        ctx.save_for_backward(v, a, S, stats)
+        ctx.temp = float(temp)
+        return loss
+
+    @staticmethod
+    @once
+    def backward(ctx, g):
+        v, a, S, stats = ctx.saved_tensors
+        B, T, C = v.shape
+        dv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        da = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        if dv is not None or da is not None:
+            check(_lib.lib().vca_sync_nce_bwd_f32(B, T, C, ptr(v), ptr(a), ptr(S), ptr(stats), ptr(_c(g)), ctx.temp,
+                                                  ptr(dv), ptr(da), stream()), 'sync_nce_bwd')
+        return dv, da, None
+
+
+class SyncCosFn(torch.autograd.Function):
+    """5 - mean_t |cos(v_t, a_t)| per sample (generator.py:348-350)."""
+
+    @staticmethod
+    def forward(ctx, v, a):
+        v, a = _c(v), _c(a)
+        B, T, C = v.shape
+        cosv = torch.empty((B, T), device=v.device, dtype=torch.float32)
+        loss = torch.empty((B,), device=v.device, dtype=torch.float32)
+        check(_lib.lib().vca_sync_cos_fwd_f32(B, T, C, ptr(v), ptr(a), ptr(cosv), ptr(loss), stream()), 'sync_cos_fwd')
+        ctx.save_for_backward(v, a, cosv)
+        return loss
+
+    @staticmethod
+    @once
+    def backward(ctx, g):
+        v, a, cosv = ctx.saved_tensors
+        B, T, C = v.shape
+        dv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        da = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        if dv is not None or da is not None:
+            check(_lib.lib().vca_sync_cos_bwd_f32(B, T, C, ptr(v), ptr(a), ptr(cosv), ptr(_c(g)), ptr(dv), ptr(da),
+                                                  stream()), 'sync_cos_bwd')
+        return dv, da
+
+
 def sync_loss(v_feat, a_feat, temp, gen):
-    """generator.py:347-361."""
-    F = torch.nn.functional
+    """generator.py:347-361: per-sample loss (B,) from the (B, T, C) visual and audio embeddings."""
     if gen:
-        return 5.0 - F.cosine_similarity(v_feat, a_feat, 2).abs().mean(1)
-    sim = torch.bmm(F.normalize(v_feat, dim=2), F.normalize(a_feat, dim=2).transpose(1, 2)) / temp
-    d_va = torch.diagonal(F.log_softmax(sim, 2), dim1=-2, dim2=-1).mean(1)
-    d_av = torch.diagonal(F.log_softmax(sim, 1), dim1=-2, dim2=-1).mean(1)
-    return -0.5 * (d_va + d_av)
+        return SyncCosFn.apply(v_feat, a_feat)
+    return SyncNceFn.apply(v_feat, a_feat, temp)
 
 
 # --------------------------------------------------------------------------- #
