@@ -195,6 +195,30 @@ int vca_softplus_bwd_f32(int n, const float* x, float sign, float scale, const f
 int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, float* out, void* stream);
 int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
                    void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Data movement on channels-last maps.
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.cat along channels with broadcasting sources (generator.py:249-250 noise | phonemes tiled over frequency,
+ * :257,262 attention merges, :312-314 conditioning vector tiled over the map): y[n][h][w] = [x1[row1] | x2[row2]],
+ * row_k = n*skn + h*skh + w*skw in rows of Ck floats (stride 0 broadcasts).  The backward call extracts channels
+ * [c0, c0+Cs) of gy into gx with the same row mapping, adding atomically when `accumulate` (broadcast source,
+ * gx zeroed by the caller). */
+int vca_concat2_f32(int N, int H, int W, int C1, int C2, const float* x1, long long s1n, long long s1h, long long s1w,
+                    const float* x2, long long s2n, long long s2h, long long s2w, float* y, void* stream);
+int vca_concat2_bwd_f32(int N, int H, int W, int C, int c0, int Cs, const float* gy, long long sn, long long sh,
+                        long long sw, int accumulate, float* gx, void* stream);
+/* y[n][c] = mean of x[n][0:wh][0:ww][c] (nn.AvgPool2d(4) with a 1x1 output, resnet.py:82; .mean([2,3]) of the
+ * discriminator heads, generator.py:310,316) and its adjoint. */
+int vca_window_mean_f32(int N, int H, int W, int C, int wh, int ww, const float* x, float* y, void* stream);
+int vca_window_mean_bwd_f32(int N, int H, int W, int C, int wh, int ww, const float* gy, float* gx, void* stream);
+/* nn.Dropout / nn.GRU(dropout=) in training mode (visual_front.py:18,20,29): counter-based generator keyed by
+ * (seed, *step_dev, element index); the byte mask is kept for the backward call. */
+int vca_dropout_f32(long long n, const float* x, float p, unsigned long long seed, const int* step_dev, float* y,
+                    unsigned char* mask, void* stream);
+int vca_dropout_bwd_f32(long long n, const float* gy, const unsigned char* mask, float p, float* gx, void* stream);
+/* F.interpolate(mel, scale_factor=1/factor, mode='bilinear') for factor 2 or 4 on [N][H][W] maps (train.py:170-171). */
+int vca_mel_down_f32(int N, int H, int W, int factor, const float* x, float* y, void* stream);
+
 /* Loss heads of sync_Discriminator.forward (generator.py:347-361) on the embeddings v, a [B][T][C] (T <= 160).
  * nce (gen=False, :352-361): loss[b] = -1/2 mean_i (log_softmax(S,2)_ii + log_softmax(S,1)_ii) with
  * S = normalize(v) normalize(a)^T / temp; S [B][T][T] and stats [B][4][T] (1/|v_i|, 1/|a_i|, row and column

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
-           'sync_loss.hip')
+           'sync_loss.hip', 'layout.hip')
 
 
 def build(force=False, verbose=False):
@@ -74,6 +74,13 @@ _SIGS = {
     'vca_sync_nce_bwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P], _I),
     'vca_sync_cos_fwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P], _I),
     'vca_sync_cos_bwd_f32': ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    'vca_concat2_f32': ([_I, _I, _I, _I, _I, _P, _LL, _LL, _LL, _P, _LL, _LL, _LL, _P, _P], _I),
+    'vca_concat2_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _LL, _LL, _LL, _I, _P, _P], _I),
+    'vca_window_mean_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    'vca_window_mean_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    'vca_dropout_f32': ([_LL, _P, _F, ctypes.c_ulonglong, _P, _P, _P, _P], _I),
+    'vca_dropout_bwd_f32': ([_LL, _P, _P, _F, _P, _P], _I),
+    'vca_mel_down_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 

@@ -1,0 +1,187 @@
+// Data-movement kernels of the step on channels-last maps: channel concatenation with broadcast (the decoder's
+// [phonemes tiled over frequency | noise] input, the attention merges, the discriminators' conditioning vector),
+// window means (AvgPool2d(4) head, spatial means of the discriminator heads), dropout, and the mel pyramid.
+#include "common.h"
+
+namespace {
+
+constexpr int THR = 256;
+
+int grid_for(size_t n) {
+  size_t g = (n + THR - 1) / THR;
+  if (g > 4096) g = 4096;
+  return g < 1 ? 1 : (int)g;
+}
+
+// y[n][h][w][0..C1) = x1[row1][.],  y[n][h][w][C1..C1+C2) = x2[row2][.], row_k = n*skn + h*skh + w*skw (a stride of 0
+// broadcasts that dimension).
+__global__ __launch_bounds__(THR) void concat2_kernel(int N, int H, int W, int C1, int C2,
+                                                      const float* __restrict__ x1, long long s1n, long long s1h,
+                                                      long long s1w, const float* __restrict__ x2, long long s2n,
+                                                      long long s2h, long long s2w, float* __restrict__ y) {
+  const int C = C1 + C2;
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    y[i] = c < C1 ? x1[(size_t)(n * s1n + h * s1h + w * s1w) * C1 + c]
+                  : x2[(size_t)(n * s2n + h * s2h + w * s2w) * C2 + (c - C1)];
+  }
+}
+
+// Adjoint of concat2 for one of the two sources: gx[row][c] (+)= gy[n][h][w][c0 + c].  A source without broadcast is
+// a plain strided copy; a broadcast source is accumulated with atomics into a zeroed gx.
+__global__ __launch_bounds__(THR) void concat2_bwd_kernel(int N, int H, int W, int C, int c0, int Cs,
+                                                          const float* __restrict__ gy, long long sn, long long sh,
+                                                          long long sw, int atomic, float* __restrict__ gx) {
+  const size_t total = (size_t)N * H * W * Cs;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % Cs);
+    size_t r = i / Cs;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const float g = gy[(((size_t)n * H + h) * W + w) * C + c0 + c];
+    float* dst = gx + (size_t)(n * sn + h * sh + w * sw) * Cs + c;
+    if (atomic) atomicAdd(dst, g);
+    else *dst = g;
+  }
+}
+
+// y[n][c] = mean over h < wh, w < ww of x[n][h][w][c]
+__global__ __launch_bounds__(THR) void window_mean_kernel(int N, int H, int W, int C, int wh, int ww,
+                                                          const float* __restrict__ x, float* __restrict__ y) {
+  const size_t total = (size_t)N * C;
+  const float inv = 1.f / (float)(wh * ww);
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / C);
+    float s = 0.f;
+    for (int h = 0; h < wh; ++h)
+      for (int w = 0; w < ww; ++w) s += x[(((size_t)n * H + h) * W + w) * C + c];
+    y[i] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(THR) void window_mean_bwd_kernel(int N, int H, int W, int C, int wh, int ww,
+                                                              const float* __restrict__ gy, float* __restrict__ gx) {
+  const size_t total = (size_t)N * H * W * C;
+  const float inv = 1.f / (float)(wh * ww);
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    gx[i] = (h < wh && w < ww) ? gy[(size_t)n * C + c] * inv : 0.f;
+  }
+}
+
+// Counter-based generator: a 64-bit mix of (seed, stream position) -> 24 uniform bits.
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.f / 16777216.f);
+}
+
+// y = keep ? x / (1-p) : 0; the keep mask is stored for the backward pass.  `step` (device word, may be NULL)
+// is mixed into the stream position so that replays of a captured graph draw fresh masks.
+__global__ __launch_bounds__(THR) void dropout_kernel(size_t n, const float* __restrict__ x, float p,
+                                                      unsigned long long seed, const int* __restrict__ step,
+                                                      float* __restrict__ y, unsigned char* __restrict__ mask) {
+  const unsigned long long base = (unsigned long long)(step ? *step : 0) << 40;
+  const float scale = 1.f / (1.f - p);
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < n; i += (size_t)gridDim.x * THR) {
+    const bool keep = uniform01(seed, base + i) >= p;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(THR) void dropout_bwd_kernel(size_t n, const float* __restrict__ gy,
+                                                          const unsigned char* __restrict__ mask, float scale,
+                                                          float* __restrict__ gx) {
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < n; i += (size_t)gridDim.x * THR)
+    gx[i] = mask[i] ? gy[i] * scale : 0.f;
+}
+
+// F.interpolate(x, scale_factor=1/f, mode='bilinear', align_corners=False) for f in {2, 4} on single-channel maps
+// (train.py:170-171): the source coordinate of output o is f*o + (f-1)/2, i.e. exactly half way between the pixels
+// f*o + f/2 - 1 and f*o + f/2, in both directions: the mean of that 2x2 block.
+__global__ __launch_bounds__(THR) void mel_down_kernel(int N, int H, int W, int f, const float* __restrict__ x,
+                                                       float* __restrict__ y) {
+  const int OH = H / f, OW = W / f;
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int ow = (int)(i % OW);
+    size_t r = i / OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int h0 = f * oh + f / 2 - 1, w0 = f * ow + f / 2 - 1;
+    const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+    const float* p = x + (size_t)n * H * W;
+    y[i] = 0.25f * (p[(size_t)h0 * W + w0] + p[(size_t)h0 * W + w1] + p[(size_t)h1 * W + w0] + p[(size_t)h1 * W + w1]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vca_concat2_f32(int N, int H, int W, int C1, int C2, const float* x1, long long s1n, long long s1h,
+                               long long s1w, const float* x2, long long s2n, long long s2h, long long s2w, float* y,
+                               void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C1 > 0 && C2 > 0 && x1 && x2 && y);
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for((size_t)N * H * W * (C1 + C2))), dim3(THR), 0, (hipStream_t)stream,
+                     N, H, W, C1, C2, x1, s1n, s1h, s1w, x2, s2n, s2h, s2w, y);
+  return vca_launch_status();
+}
+
+extern "C" int vca_concat2_bwd_f32(int N, int H, int W, int C, int c0, int Cs, const float* gy, long long sn,
+                                   long long sh, long long sw, int accumulate, float* gx, void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && c0 >= 0 && Cs > 0 && c0 + Cs <= C && gy && gx);
+  hipLaunchKernelGGL(concat2_bwd_kernel, dim3(grid_for((size_t)N * H * W * Cs)), dim3(THR), 0, (hipStream_t)stream, N,
+                     H, W, C, c0, Cs, gy, sn, sh, sw, accumulate, gx);
+  return vca_launch_status();
+}
+
+extern "C" int vca_window_mean_f32(int N, int H, int W, int C, int wh, int ww, const float* x, float* y, void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && wh > 0 && wh <= H && ww > 0 && ww <= W && x && y);
+  hipLaunchKernelGGL(window_mean_kernel, dim3(grid_for((size_t)N * C)), dim3(THR), 0, (hipStream_t)stream, N, H, W, C,
+                     wh, ww, x, y);
+  return vca_launch_status();
+}
+
+extern "C" int vca_window_mean_bwd_f32(int N, int H, int W, int C, int wh, int ww, const float* gy, float* gx,
+                                       void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && wh > 0 && wh <= H && ww > 0 && ww <= W && gy && gx);
+  hipLaunchKernelGGL(window_mean_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(THR), 0, (hipStream_t)stream,
+                     N, H, W, C, wh, ww, gy, gx);
+  return vca_launch_status();
+}
+
+extern "C" int vca_dropout_f32(long long n, const float* x, float p, unsigned long long seed, const int* step_dev,
+                               float* y, unsigned char* mask, void* stream) {
+  VCA_CHECK_ARG(n > 0 && x && y && mask && p >= 0.f && p < 1.f);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)n)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, x, p,
+                     seed, step_dev, y, mask);
+  return vca_launch_status();
+}
+
+extern "C" int vca_dropout_bwd_f32(long long n, const float* gy, const unsigned char* mask, float p, float* gx,
+                                   void* stream) {
+  VCA_CHECK_ARG(n > 0 && gy && mask && gx && p >= 0.f && p < 1.f);
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)n)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, gy,
+                     mask, 1.f / (1.f - p), gx);
+  return vca_launch_status();
+}
+
+extern "C" int vca_mel_down_f32(int N, int H, int W, int factor, const float* x, float* y, void* stream) {
+  VCA_CHECK_ARG(N > 0 && (factor == 2 || factor == 4) && H >= factor && W >= factor && x && y);
+  hipLaunchKernelGGL(mel_down_kernel, dim3(grid_for((size_t)N * (H / factor) * (W / factor))), dim3(THR), 0,
+                     (hipStream_t)stream, N, H, W, factor, x, y);
+  return vca_launch_status();
+}

@@ -181,17 +181,17 @@ class Decoder(nn.Module):
         if noise is None:
             noise = torch.randn([B, 128, 20, T])
         noise = noise.to(x.device).permute(0, 2, 3, 1)
-        h = torch.cat([x.unsqueeze(1).expand(B, 20, T, 512), noise], 3).contiguous()   # (B, 20, T, 640)
+        h = ops.concat2(x, noise, B, 20, T)                               # (B, 20, T, 640): phonemes tiled | noise
         for block in self.decode:
             h = block(h)
         for block in self.g1:
             h = block(h)
         g1 = h
-        h = _conv(torch.cat([h, self.att1(ctx, g1, len)], 3), self.attconv1)
+        h = _conv(ops.concat2(h, self.att1(ctx, g1, len), B, h.shape[1], h.shape[2]), self.attconv1)
         for block in self.g2:
             h = block(h)
         g2 = h
-        h = _conv(torch.cat([h, self.att2(ctx, g2, len)], 3), self.attconv2)
+        h = _conv(ops.concat2(h, self.att2(ctx, g2, len), B, h.shape[1], h.shape[2]), self.attconv2)
         for block in self.g3:
             h = block(h)
         return self._mel(self.to_mel1, g1), self._mel(self.to_mel2, g2), self._mel(self.to_mel3, h)
@@ -224,11 +224,11 @@ class Discriminator(nn.Module):
         for blk in list(self.main)[1:]:
             h = blk(h)
         u = _conv(ops.leaky(h), self.uncond[1])
-        u = ops.linear(ops.leaky(u).mean([1, 2]), self.uncond[4].weight, self.uncond[4].bias)
-        cvec = c.mean(2)[:, None, None, :].expand(B, 5, f_len, 512)
-        o = _conv(ops.leaky(torch.cat([h, cvec], 3)), self.cond[1])
+        u = ops.linear(ops.spatial_mean(ops.leaky(u)), self.uncond[4].weight, self.uncond[4].bias)
+        cvec = ops.WindowMeanFn.apply(c.reshape(B * 512, 1, c.size(2), 1), 1, c.size(2)).view(B, 512)   # c.mean(2)
+        o = _conv(ops.leaky(ops.concat2(h, cvec, B, 5, f_len)), self.cond[1])
         o = _conv(ops.leaky(o), self.cond[3])
-        o = ops.linear(ops.leaky(o).mean([1, 2]), self.cond[6].weight, self.cond[6].bias)
+        o = ops.linear(ops.spatial_mean(ops.leaky(o)), self.cond[6].weight, self.cond[6].bias)
         return u.view(B, -1), o.view(B, -1)
 
 

@@ -26,7 +26,7 @@ class Visual_front(nn.Module):
         f = ops.bn_act(f, self.frontend[1], self.frontend[2], stats=stats)
         f = ops.maxpool3x3s2(f.view(B * T, f.shape[2], f.shape[3], 64))              # frames flattened for free
         f = self.resnet(f)                                                           # (B*T, 512)
-        f = self.dropout(f).view(B, T, 512)
+        f = ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
         sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)
         sent = ops.linear(sent, self.fc.weight, self.fc.bias)                        # (B, T, 512)
         return f, sent.transpose(1, 2).contiguous()

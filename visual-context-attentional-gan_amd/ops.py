@@ -659,14 +659,160 @@ def maxpool3x3s2(x):
     return MaxPool3Fn.apply(x)
 
 
+class WindowMeanFn(torch.autograd.Function):
+    """(N,H,W,C) -> (N,C): mean over the window [0:wh, 0:ww]."""
+
+    @staticmethod
+    def forward(ctx, x, wh, ww):
+        x = _c(x)
+        n, h, w, c = x.shape
+        ctx.geom = (n, h, w, c, wh, ww)
+        y = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        check(_lib.lib().vca_window_mean_f32(n, h, w, c, wh, ww, ptr(x), ptr(y), stream()), 'window_mean')
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return WindowMeanBwdFn.apply(gy, ctx.geom), None, None
+
+
+class WindowMeanBwdFn(torch.autograd.Function):
+    """The adjoint of WindowMeanFn (linear, so its own backward is WindowMeanFn: R1 differentiates through the
+    spatial mean of the unconditional head twice)."""
+
+    @staticmethod
+    def forward(ctx, gy, geom):
+        n, h, w, c, wh, ww = geom
+        ctx.geom = geom
+        gx = torch.empty((n, h, w, c), device=gy.device, dtype=torch.float32)
+        check(_lib.lib().vca_window_mean_bwd_f32(n, h, w, c, wh, ww, ptr(_c(gy)), ptr(gx), stream()), 'window_mean_bwd')
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        return WindowMeanFn.apply(ggx, ctx.geom[4], ctx.geom[5]), None
+
+
+def spatial_mean(x):
+    """(N,H,W,C) -> (N,C), the .mean([2,3]) of generator.py:310,316."""
+    return WindowMeanFn.apply(x, x.shape[1], x.shape[2])
+
+
 def head_pool4(x):
     """nn.AvgPool2d(4) of resnet.py:82 on a channels-last map whose output is 1x1: the mean of the top-left 4x4
     window when the map is at least 4 wide, the global mean otherwise (96x96 / 48x48 clips)."""
     n, h, w, c = x.shape
     if h >= 4 and w >= 4:
         assert h < 8 and w < 8, 'AvgPool2d(4) output must be 1x1 (visual_front.py:30)'
-        return x[:, :4, :4].mean((1, 2))
-    return x.mean((1, 2))
+        return WindowMeanFn.apply(x, 4, 4)
+    return WindowMeanFn.apply(x, h, w)
+
+
+def _row_strides(t, n, h, w):
+    """Row strides (in rows of C floats) of a source given as (N,H,W,C), (N,W,C) [broadcast over H] or (N,C)
+    [broadcast over H and W]."""
+    if t.dim() == 4:
+        assert t.shape[:3] == (n, h, w), (t.shape, n, h, w)
+        return h * w, w, 1
+    if t.dim() == 3:
+        assert t.shape[:2] == (n, w), (t.shape, n, w)
+        return w, 0, 1
+    assert t.dim() == 2 and t.shape[0] == n
+    return 1, 0, 0
+
+
+class Concat2Fn(torch.autograd.Function):
+    """Channel concatenation of two channels-last sources, either of which may be broadcast over H (given as
+    (N,W,C)) or over H and W (given as (N,C))."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, n, h, w):
+        x1, x2 = _c(x1), _c(x2)
+        c1, c2 = x1.shape[-1], x2.shape[-1]
+        s1, s2 = _row_strides(x1, n, h, w), _row_strides(x2, n, h, w)
+        y = torch.empty((n, h, w, c1 + c2), device=x1.device, dtype=torch.float32)
+        check(_lib.lib().vca_concat2_f32(n, h, w, c1, c2, ptr(x1), *s1, ptr(x2), *s2, ptr(y), stream()), 'concat2')
+        ctx.meta = (n, h, w, c1, c2, s1, s2, x1.shape, x2.shape)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        n, h, w, c1, c2, s1, s2, sh1, sh2 = ctx.meta
+        gy = _c(gy)
+        outs = []
+        for k, (c0, cs, st, shp) in enumerate(((0, c1, s1, sh1), (c1, c2, s2, sh2))):
+            if not ctx.needs_input_grad[k]:
+                outs.append(None)
+                continue
+            bcast = len(shp) < 4
+            gx = (torch.zeros if bcast else torch.empty)(shp, device=gy.device, dtype=torch.float32)
+            check(_lib.lib().vca_concat2_bwd_f32(n, h, w, c1 + c2, c0, cs, ptr(gy), *st, 1 if bcast else 0, ptr(gx),
+                                                 stream()), 'concat2_bwd')
+            outs.append(gx)
+        return outs[0], outs[1], None, None, None
+
+
+def concat2(x1, x2, n, h, w):
+    return Concat2Fn.apply(x1, x2, n, h, w)
+
+
+_rng_step = {}      # device -> int32 word mixed into every dropout stream; advanced once per training step
+_rng_calls = [0]    # dropout call sites seen since the last advance (distinct seeds within a step)
+_rng_seed = [0x5EED]
+
+
+def rng_advance(device):
+    """Move every dropout stream on: call once per training step (a device-side add, so it is captured with the
+    step and replays draw fresh masks)."""
+    t = _rng_step.get(device)
+    if t is None:
+        t = _rng_step[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    t.add_(1)
+    _rng_calls[0] = 0
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _c(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        step = _rng_step.get(x.device)
+        if step is None:
+            step = _rng_step[x.device] = torch.zeros(1, device=x.device, dtype=torch.int32)
+        _rng_calls[0] += 1
+        seed = (_rng_seed[0] * 0x9E3779B1 + _rng_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        check(_lib.lib().vca_dropout_f32(x.numel(), ptr(x), float(p), seed, step.data_ptr(), ptr(y), mask.data_ptr(),
+                                         stream()), 'dropout')
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        mask, = ctx.saved_tensors
+        gx = torch.empty(gy.shape, device=gy.device, dtype=torch.float32)
+        check(_lib.lib().vca_dropout_bwd_f32(gy.numel(), ptr(_c(gy)), mask.data_ptr(), ctx.p, ptr(gx), stream()),
+              'dropout_bwd')
+        return gx, None
+
+
+def dropout(x, p, training):
+    """nn.Dropout / F.dropout: identity in eval mode or with p = 0."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+def mel_down(mel, factor):
+    """F.interpolate(mel, scale_factor=1/factor, mode='bilinear') of a (B,1,F,M) mel for factor 2 or 4."""
+    b, one, f, m = mel.shape
+    assert one == 1
+    y = torch.empty((b, 1, f // factor, m // factor), device=mel.device, dtype=torch.float32)
+    check(_lib.lib().vca_mel_down_f32(b, f, m, factor, ptr(_c(mel)), ptr(y), stream()), 'mel_down')
+    return y
 
 
 # --------------------------------------------------------------------------- #
@@ -851,7 +997,7 @@ def gru(x, mod, training):
                     getattr(mod, 'bias_ih_l%d%s' % (layer, sfx)), getattr(mod, 'bias_hh_l%d%s' % (layer, sfx))]
         h = GruLayerFn.apply(h, *wts)
         if training and mod.dropout > 0 and layer + 1 < mod.num_layers:
-            h = torch.nn.functional.dropout(h, mod.dropout, True)
+            h = dropout(h, mod.dropout, True)
     return h.transpose(0, 1)
 
 

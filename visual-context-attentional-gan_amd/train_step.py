@@ -82,8 +82,9 @@ class GanStep:
         """Forward of the generator side, discriminator losses and their backward (train.py:170-210)."""
         m = self.m
         self._zero(G_NAMES)
-        mel1 = F.interpolate(mel, scale_factor=0.25, mode='bilinear', align_corners=False)
-        mel2 = F.interpolate(mel, scale_factor=0.5, mode='bilinear', align_corners=False)
+        ops.rng_advance(mel.device)
+        mel1 = ops.mel_down(mel, 4)          # F.interpolate(mel, scale_factor=0.25, mode='bilinear'), train.py:170
+        mel2 = ops.mel_down(mel, 2)
         phon, sent = m['v_front'](vid)
         g1, g2, g3 = m['gen'](sent, phon, vid_len, noise=noise)
         reals = [t.detach().clone().requires_grad_(True) for t in (mel1, mel2, mel)]
