@@ -940,10 +940,23 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.co_tiles = (d->Cout + tile_c - 1) / tile_c;
   const int ci_tiles = (d->Cin + tile_c - 1) / tile_c;
   const int out_tiles = a.co_tiles * ci_tiles;
-  int split = ((quad ? 1024 : 2048) + out_tiles - 1) / out_tiles;
-  if (split > (quad ? 512 : 256)) split = quad ? 512 : 256;   // bounds the atomic adds that land on one dW tile
-  if (split > a.ntiles) split = a.ntiles;
-  if (split < 1) split = 1;
+  // Pixel split: every workgroup ends with one atomic add per accumulator, which costs about as much as `fin`
+  // patches of MFMA work, and the launch runs in ceil(workgroups / resident slots) rounds.  Take the split that
+  // minimises rounds * (patches per workgroup + fin).
+  const int slots = quad ? 512 : 256;            // 2 x 4-wave or 1 x 8-wave workgroups per CU
+  const double fin = quad ? 2.0 : 1.0;
+  int split = 1;
+  double best_cost = 1e300;
+  for (int sp = 1; sp <= a.ntiles && sp <= 512; ++sp) {
+    const int ppb = (a.ntiles + sp - 1) / sp;
+    const int sp_eff = (a.ntiles + ppb - 1) / ppb;
+    const long long blocks = (long long)out_tiles * sp_eff;
+    const double cost = (double)((blocks + slots - 1) / slots) * (ppb + fin);
+    if (cost < best_cost) {
+      best_cost = cost;
+      split = sp_eff;
+    }
+  }
   a.tiles_per_block = (a.ntiles + split - 1) / split;
   split = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
