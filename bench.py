@@ -61,11 +61,11 @@ def roofline_probe(device, dtype):
     issued = ach * MFMA_PER_PRODUCT[dtype]          # matrix-core work actually issued (3 bf16 MFMAs per product)
     kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else 'conv_bf16_halo_kernel<128,2,2,%d>' % MFMA_PER_PRODUCT[dtype]
     # HBM-side bytes per launch of this kernel on this layer from separate rocprofv3 --pmc passes
-    # (profiles/r1_decode0conv1_pmc.txt): 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE, in KiB.
+    # (profiles/r1_decode0conv1_pmc_v2.txt): 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE, in KiB.
     # Algorithmic bytes (input + packed weights + output, each once) are 123 + 33 + 98 = 254 MB; the excess is the
     # input halo re-read once per 128-channel output block and the weight stream re-read per pixel block, which the
     # 256 MiB Infinity Cache absorbs (the counters sit on the L2's fabric side and include its hits).
-    traffic = (2 * 649223 + 96000) * 1024 if dtype in ('bf16x3', 'mixed') else None
+    traffic = (2 * 653092 + 96000) * 1024 if dtype in ('bf16x3', 'mixed') else None
     return dict(bound='mfma', kernel=kern + ' on decode.0.conv1', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
                 issued_frac=round(issued / peak, 4), traffic=traffic, launch_ms=round(dt * 1e3, 3),
