@@ -111,7 +111,9 @@ int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, co
  * residual adds and the 1/sqrt(2) scaling at: visual_front.py:12-13, resnet.py:34-64,
  * generator.py:22-49,77-92,105-131,179-180,208-225,325-333.
  * ---------------------------------------------------------------------------------------------- */
-/* sums[0..C) += sum_p (x[p][c] - x[0][c]);  sums[C..2C) += sum_p (x[p][c] - x[0][c])^2   (caller zeroes) */
+/* sums[0..C) = sum_p (x[p][c] - x[0][c]);  sums[C..2C) = sum_p (x[p][c] - x[0][c])^2.  sums holds VCA_BN_SLOTS*2*C
+ * floats, zeroed by the caller: the part behind the first 2*C is scratch for per-workgroup partial sums. */
+#define VCA_BN_SLOTS 16
 int vca_colstats_f32(int P, int C, const float* x, float* sums, void* stream);
 
 /* Train-mode statistics -> mean, 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale; updates the
@@ -132,8 +134,9 @@ int vca_affine_act_f32(int P, int C, const float* x, const float* scale, const f
                        const float* res, int act, float slope, float oscale, float* y, void* stream);
 
 /* Backward of vca_affine_act_f32.  With gz = gy*oscale*act'(z):
- *   sums (3*C, zeroed by the caller; may be NULL when train == 0 and act != PReLU) receives
- *     sum gz, sum gz*xhat (xhat = (x-mean)*invstd) and sum gy*oscale*min(z,0)  = d beta, d gamma, d alpha;
+ *   sums (VCA_BN_SLOTS*3*C floats, zeroed by the caller; may be NULL when train == 0 and act != PReLU): the
+ *     first 3*C receive sum gz, sum gz*xhat (xhat = (x-mean)*invstd) and sum gy*oscale*min(z,0)
+ *     = d beta, d gamma, d alpha; the rest is scratch for per-workgroup partial sums;
  *   gx   = scale*(gz - mean(gz) - xhat*mean(gz*xhat)) when train != 0 (batch statistics), scale*gz otherwise;
  *   gres = gz.   gx / gres may be NULL. */
 int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const float* scale, const float* shift,

@@ -17,9 +17,12 @@ x = torch.randn(N, H, W, Cin, device=dev)
 w = torch.randn(Cout, Cin, K, K, device=dev) * 0.02
 cfg = ops.ConvCfg(w.shape, x.shape, stride, (K // 2, K // 2), 0)
 gy = torch.randn(cfg.yshape, device=dev)
+stats = torch.zeros(2, Cout, device=dev) if os.environ.get('STATS') else None
+
+
 def run():
     if kind == 'fwd':
-        ops._conv_fwd_raw(x, w, None, cfg)
+        ops._conv_fwd_raw(x, w, None, cfg, stats)
     elif kind == 'dgrad':
         ops._conv_dgrad_raw(gy, w, cfg)
     else:

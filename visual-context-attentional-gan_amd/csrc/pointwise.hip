@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int THR = 256;
+constexpr int BN_SLOTS = 16;   // partial-sum buffers of the batch-norm backward reduction
 
 struct RowMap {
   int tx, ty, TX, TY;  // this thread's float4 column / row slot, and the workgroup's layout
@@ -43,6 +44,16 @@ __device__ __forceinline__ float act_grad(float z, int act, float slope) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// sums[0][.] += sums[1..BN_SLOTS)[.]
+__global__ void bn_fold_slots_kernel(int n, float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float t = sums[i];
+  for (int k = 1; k < BN_SLOTS; ++k) t += sums[(size_t)k * n + i];
+  sums[i] = t;
+}
+
+// ---------------------------------------------------------------------------------------------
 // column statistics: out[0..C) = sum (x - pivot), out[C..2C) = sum (x - pivot)^2, pivot = x[0][c]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(THR) void colstats_kernel(int P, int C, const float* __restrict__ x,
@@ -72,10 +83,11 @@ __global__ __launch_bounds__(THR) void colstats_kernel(int P, int C, const float
         s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
       }
       const int col = (c0 + m.tx) * 4;
-      atomicAdd(out + col + 0, s1.x); atomicAdd(out + col + 1, s1.y);
-      atomicAdd(out + col + 2, s1.z); atomicAdd(out + col + 3, s1.w);
-      atomicAdd(out + C + col + 0, s2.x); atomicAdd(out + C + col + 1, s2.y);
-      atomicAdd(out + C + col + 2, s2.z); atomicAdd(out + C + col + 3, s2.w);
+      float* dst = out + (size_t)(blockIdx.x % BN_SLOTS) * 2 * C;   // partial buffers: see bn_act_bwd_reduce_kernel
+      atomicAdd(dst + col + 0, s1.x); atomicAdd(dst + col + 1, s1.y);
+      atomicAdd(dst + col + 2, s1.z); atomicAdd(dst + col + 3, s1.w);
+      atomicAdd(dst + C + col + 0, s2.x); atomicAdd(dst + C + col + 1, s2.y);
+      atomicAdd(dst + C + col + 2, s2.z); atomicAdd(dst + C + col + 3, s2.w);
     }
     __syncthreads();
   }
@@ -241,8 +253,10 @@ __global__ __launch_bounds__(THR) void bn_act_bwd_reduce_kernel(BwArgs a) {
           t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
         }
         if (k < 2 || a.act == VCA_ACT_PRELU) {
-          atomicAdd(a.sums + k * a.C + col + 0, t.x); atomicAdd(a.sums + k * a.C + col + 1, t.y);
-          atomicAdd(a.sums + k * a.C + col + 2, t.z); atomicAdd(a.sums + k * a.C + col + 3, t.w);
+          // one of BN_SLOTS partial buffers per workgroup: atomics on one cache line serialise in L2, and a
+          // thousand workgroups adding to the same 3*C words would otherwise set the kernel's duration
+          float* dst = a.sums + (size_t)(blockIdx.x % BN_SLOTS) * 3 * a.C + k * a.C + col;
+          atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
         }
       }
     }
@@ -401,6 +415,7 @@ extern "C" int vca_colstats_f32(int P, int C, const float* x, float* sums, void*
   int g = (P + TY - 1) / TY;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(colstats_kernel, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, sums);
+  hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, 2 * C, sums);
   return vca_launch_status();
 }
 
@@ -451,6 +466,7 @@ extern "C" int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float
     int g = (P + TY - 1) / TY;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(g), dim3(THR), 0, s, a);
+    hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((3 * C + 127) / 128), dim3(128), 0, s, 3 * C, sums);
   }
   if (gx || gres)
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 4))), dim3(THR), 0, s, a);

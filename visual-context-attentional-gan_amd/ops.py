@@ -444,16 +444,16 @@ class BnActFn(torch.autograd.Function):
         P, C = _pc(x)
         gy = _c(gy)
         need_sums = coef is not None or act == ACT_PRELU
-        sums = torch.zeros((3, C), device=x.device, dtype=torch.float32) if need_sums else None
+        sums = torch.zeros((16, 3, C), device=x.device, dtype=torch.float32) if need_sums else None   # VCA_BN_SLOTS
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
         mean, invstd, sc, sh = (coef[0], coef[1], coef[2], coef[3]) if coef is not None else (None,) * 4
         check(_lib.lib().vca_affine_act_bwd_f32(P, C, ptr(gy), ptr(x), ptr(sc), ptr(sh), ptr(alpha), ptr(res),
                                                 ptr(mean), ptr(invstd), act, slope, oscale, 1 if train else 0,
                                                 ptr(sums), ptr(gx), ptr(gres), stream()), 'affine_act_bwd')
-        ggamma = sums[1] if (coef is not None and has_g) else None
-        gbeta = sums[0] if (coef is not None and has_b) else None
-        galpha = sums[2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
+        ggamma = sums[0, 1] if (coef is not None and has_g) else None
+        gbeta = sums[0, 0] if (coef is not None and has_b) else None
+        galpha = sums[0, 2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
         return gx, ggamma, gbeta, galpha, gres, None, None, None, None, None
 
 
@@ -466,7 +466,7 @@ def _bn_coef(x, bn, stats=None):
     if bn.training or bn.running_mean is None:
         pivot = None
         if stats is None:
-            sums = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+            sums = torch.zeros((16, 2, C), device=x.device, dtype=torch.float32)   # VCA_BN_SLOTS partial buffers
             pivot = _c(x.detach())
             check(L.vca_colstats_f32(P, C, ptr(pivot), ptr(sums), stream()), 'colstats')
         elif isinstance(stats, BnStats):
