@@ -222,6 +222,25 @@ int vca_dropout_bwd_f32(long long n, const float* gy, const unsigned char* mask,
 /* F.interpolate(mel, scale_factor=1/factor, mode='bilinear') for factor 2 or 4 on [N][H][W] maps (train.py:170-171). */
 int vca_mel_down_f32(int N, int H, int W, int factor, const float* x, float* y, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Waveform <-> spectrogram path of validation (src/data/stft.py, audio_processing.py, vid_aud_grid.py:190-232).
+ * The windowed-DFT contractions themselves are vca_conv_fwd_f32 calls (see audio.py); these are the kernels around
+ * them.  spec / rect rows are [real F | imaginary F] per frame; mag / phase are (B, F, T) like the reference.
+ * ---------------------------------------------------------------------------------------------- */
+/* F.pad(x, (pad, pad), mode='reflect') into rows of pitch Lrow (zero-filled tail), stft.py:75-79 */
+int vca_reflect_pad_f32(int B, int L, int pad, int Lrow, const float* x, float* y, void* stream);
+/* magnitude = sqrt(re^2 + im^2), phase = atan2(im, re) (phase may be NULL), stft.py:88-94 */
+int vca_mag_phase_f32(int B, int T, int F, const float* spec, float* mag, float* phase, void* stream);
+/* [mag cos(phase) | mag sin(phase)], stft.py:99-100 */
+int vca_polar_to_rect_f32(int B, int T, int F, const float* mag, const float* phase, float* rect, void* stream);
+/* one Griffin-Lim projection: the phase of `spec` with the magnitude `mag`, audio_processing.py:62-64 */
+int vca_gl_project_f32(int B, int T, int F, const float* spec, const float* mag, float* rect, void* stream);
+/* y = ola[pad : pad+Lout] / window_sum (where > tiny) * scale, stft.py:108-127 */
+int vca_istft_finish_f32(int B, int Lrow, int Lout, int pad, float scale, float tiny, const float* ola,
+                         const float* wsum, float* y, void* stream);
+/* y[n] = x[n] + coef*y[n-1], clipped to [-1, 1]: lfilter([1], [1, -coef]) + np.clip, vid_aud_grid.py:203-210,230-232 */
+int vca_deemphasis_clip_f32(int B, int L, float coef, const float* x, float* y, void* stream);
+
 /* Loss heads of sync_Discriminator.forward (generator.py:347-361) on the embeddings v, a [B][T][C] (T <= 160).
  * nce (gen=False, :352-361): loss[b] = -1/2 mean_i (log_softmax(S,2)_ii + log_softmax(S,1)_ii) with
  * S = normalize(v) normalize(a)^T / temp; S [B][T][T] and stats [B][4][T] (1/|v_i|, 1/|a_i|, row and column

@@ -122,6 +122,20 @@ class ConvCfg:
 _exact_bwd = [False]   # True while a backward runs under create_graph (its results feed a loss value: R1 penalty)
 
 
+class use_precision:
+    """Context manager: run the enclosed matrix-core convolutions at the given precision."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _precision[0]
+        set_precision(self.mode)
+
+    def __exit__(self, *exc):
+        _precision[0] = self.prev
+
+
 def _nsplit(backward=False):
     if _precision[0] == 'mixed':
         return 1 if (backward and not _exact_bwd[0]) else 3
