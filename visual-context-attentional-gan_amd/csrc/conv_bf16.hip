@@ -131,13 +131,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   };
   // the tile requested at the start of a tap must have landed before the barrier that ends the tap
   auto wait_b = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
-  const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
-  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
-    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
-    // ---- stage the halo of this 32-channel slice
-    for (int it = tid; it < npos_total * 2; it += 256) {
-      const int pos = it >> 1, half = it & 1;
+  // Halo staging plan of this thread, the same for every channel slice: up to 3 (position, 16-channel half) items
+  // with the element offset of the source pixel (-1: padding / outside the image / dilation hole).
+  constexpr int NHI = (2 * MAXPOS + 255) / 256;
+  long long hsrc[NHI];
+#pragma unroll
+  for (int k = 0; k < NHI; ++k) {
+    const int it = tid + k * 256;
+    hsrc[k] = -1;
+    if (it < npos_total * 2) {
+      const int pos = it >> 1;
       const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
       const int hy = rp / a.HW, hx = rp - hy * a.HW;
       int n, oy0, ox0;
@@ -152,12 +155,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
       ok = ok && vy < He && vx < We;
       vy >>= d.ups;
       vx >>= d.ups;
+      if (ok) hsrc[k] = ((long long)(n * d.Hin + vy) * d.Win + vx) * d.Cin;
+    }
+  }
+
+  const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
+  const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
+  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
+    // ---- stage the halo of this 32-channel slice
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      const int it = tid + k * 256;
+      if (it >= npos_total * 2) break;
+      const int pos = it >> 1, half = it & 1;
+      const bool ok = hsrc[k] >= 0;
       const int ci0 = chunk * 32 + half * 16;
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = 0.f;
       if (ok && ci0 < d.Cin) {
-        const float* src = a.x + ((size_t)(n * d.Hin + vy) * d.Win + vx) * d.Cin + ci0;
+        const float* src = a.x + hsrc[k] + ci0;
         if (a.vecA && ci0 + 16 <= d.Cin) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
