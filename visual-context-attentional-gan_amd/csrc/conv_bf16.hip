@@ -327,6 +327,7 @@ struct WArgs {
   int NI, TH, TW, HH, HW, NPOS;
   int tiles_x, tiles_y, nsub, ntiles, tiles_per_block, co_tiles;
   int vecA, vecB;
+  int slot_off;  // byte offset of the per-patch slot table behind the staged images in LDS
 };
 
 __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
@@ -382,19 +383,43 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // Staging plan, the same for every patch: which (slot, halo row, halo column) each of this thread's halo items
+  // covers and which output pixel its output-gradient item covers.  Only the slots' image / origin change from
+  // patch to patch; they are worked out once per patch by the first NI threads (slot_info).
+  int (*slot_info)[4] = reinterpret_cast<int (*)[4]>(smem + a.slot_off);   // [BM]: n, oy0, ox0, valid
+  constexpr int NHI = (2 * MAXPOS + 511) / 512;
+  int h_img[NHI], h_y[NHI], h_x[NHI];
+#pragma unroll
+  for (int k = 0; k < NHI; ++k) {
+    const int pos = (tid + k * 512) >> 1;
+    h_img[k] = pos / a.NPOS;
+    const int rp = pos - h_img[k] * a.NPOS;
+    h_y[k] = rp / a.HW;
+    h_x[k] = rp - h_y[k] * a.HW;
+  }
+  const int g_m = tid >> 2, g_qt = tid & 3;
+  const int g_img = g_m / tpix, g_ty = (g_m - g_img * tpix) / a.TW, g_tx = (g_m - g_img * tpix) - g_ty * a.TW;
+
   const int pt_beg = blockIdx.y * a.tiles_per_block;
   const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
   for (int pt = pt_beg; pt < pt_end; ++pt) {
     const int sid0 = pt * a.NI;
-    __syncthreads();
-    // ---- input halo of this patch, channels ci_base .. ci_base+31
-    for (int it = tid; it < npos_total * 2; it += 512) {
-      const int pos = it >> 1, half = it & 1;
-      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
-      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+    if (tid < a.NI) {
       int n, oy0, ox0;
-      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
-      int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
+      const bool sv = slot_origin(sid0 + tid, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      slot_info[tid][0] = n; slot_info[tid][1] = oy0; slot_info[tid][2] = ox0; slot_info[tid][3] = sv;
+    }
+    __syncthreads();   // slot_info visible; the previous patch's fragments have been read
+    // ---- input halo of this patch, channels ci_base .. ci_base+31
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      const int it = tid + k * 512;
+      if (it >= npos_total * 2) break;
+      const int pos = it >> 1, half = it & 1;
+      const int img = h_img[k];
+      const int n = slot_info[img][0], oy0 = slot_info[img][1], ox0 = slot_info[img][2];
+      const bool sv = slot_info[img][3] != 0;
+      int vy = oy0 * d.stride + h_y[k] - d.pad_h, vx = ox0 * d.stride + h_x[k] - d.pad_w;
       const bool ok = sv && vy >= 0 && vx >= 0 && vy < He && vx < We;
       vy >>= d.ups;
       vx >>= d.ups;
@@ -441,17 +466,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
     }
     // ---- output-gradient tile [128 pixels][32 co]: 4 threads per pixel, 8 channels each
     {
-      const int m = tid >> 2, qt = tid & 3;
-      const int img = m / tpix, rem = m - img * tpix;
-      const int ty = rem / a.TW, tx = rem - ty * a.TW;
-      int n, oy0, ox0;
-      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
-      const int oy = oy0 + ty, ox = ox0 + tx;
+      const int m = g_m, qt = g_qt;
+      const int img = min(g_img, BM - 1);
+      const int n = slot_info[img][0];
+      const bool sv = slot_info[img][3] != 0;
+      const int oy = slot_info[img][1] + g_ty, ox = slot_info[img][2] + g_tx;
       const int c0 = co_base + qt * 8;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (img < a.NI && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+      if (g_img < a.NI && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
         const float* src = a.gy + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.Cout + c0;
         if (a.vecB && c0 + 8 <= d.Cout) {
           const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
@@ -937,11 +961,11 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.x = x; a.gy = gy; a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.dw = dwpack;
   a.Cout4 = (d->Cout + 3) & ~3;
   a.ntaps = d->KH * d->KW;
-  // at most 9 taps: 64 x 64 tiles, one quadrant per wave (halo of at most 192 positions keeps two workgroups
-  // per CU; a patch that needs more, e.g. many 3x3 maps, may take the CU's LDS alone if that wastes fewer MFMAs)
+  // at most 9 taps: 64 x 64 tiles, one quadrant per wave
   const bool quad = a.ntaps <= 9;
   TileChoice t;
   if (quad) {
+    // 192 halo positions x 256 B + 32 KiB output-gradient tile = 80 KiB: two workgroups per CU
     t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, 128, 192, 12.0);
   } else {
     t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
@@ -979,7 +1003,8 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   split = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
   a.vecB = (d->Cout % 4 == 0) ? 1 : 0;
-  const size_t lds = ((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1);
+  a.slot_off = (int)(((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1));
+  const size_t lds = (size_t)a.slot_off + (quad ? 0 : BM * 4 * sizeof(int));   // (the 4-wave kernel keeps no table)
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
