@@ -241,6 +241,17 @@ int vca_istft_finish_f32(int B, int Lrow, int Lout, int pad, float scale, float 
 /* y[n] = x[n] + coef*y[n-1], clipped to [-1, 1]: lfilter([1], [1, -coef]) + np.clip, vid_aud_grid.py:203-210,230-232 */
 int vca_deemphasis_clip_f32(int B, int L, float coef, const float* x, float* y, void* stream);
 
+/* Dataset video transform, vid_aud_grid.py:94-121 (build_tensor), on decoded RGB frames [B][Tin][H0][W0][3]:
+ * crop at (crop_l, crop_u), Pillow-exact antialiased bilinear resize to OH x OW with the fixed-point coefficient
+ * tables (xmin/xcnt/xk per output column, ymin/ycnt/yk per output row, K taps each, 22 fractional bits), optional
+ * horizontal flip per clip, RGB -> L, /255, (x - mean)/std, erase box of erase_size at erase[b] = (x_s, y_s), frames
+ * t >= len[b] zero.  out is the (B, 1, Tout, OH, OW) volume Visual_front.forward takes. */
+int vca_build_video_f32(int B, int Tin, int Tout, int H0, int W0, int OH, int OW, int K, int crop_l, int crop_u,
+                        float mean, float std, const unsigned char* frames, const int* xmin, const int* xcnt,
+                        const int* xk, const int* ymin, const int* ycnt, const int* yk, const int* start,
+                        const int* len, const unsigned char* flip, const int* erase, int erase_size, float* out,
+                        void* stream);
+
 /* Loss heads of sync_Discriminator.forward (generator.py:347-361) on the embeddings v, a [B][T][C] (T <= 160).
  * nce (gen=False, :352-361): loss[b] = -1/2 mean_i (log_softmax(S,2)_ii + log_softmax(S,1)_ii) with
  * S = normalize(v) normalize(a)^T / temp; S [B][T][T] and stats [B][4][T] (1/|v_i|, 1/|a_i|, row and column

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
-           'sync_loss.hip', 'layout.hip', 'audio.hip')
+           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip')
 
 
 def build(force=False, verbose=False):
@@ -87,6 +87,7 @@ _SIGS = {
     'vca_gl_project_f32': ([_I, _I, _I, _P, _P, _P, _P], _I),
     'vca_istft_finish_f32': ([_I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     'vca_deemphasis_clip_f32': ([_I, _I, _F, _P, _P, _P], _I),
+    'vca_build_video_f32': ([_I] * 10 + [_F, _F] + [_P] * 11 + [_I, _P, _P], _I),
     'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 

@@ -1,0 +1,99 @@
+"""GPU side of the dataset's video transform (vid_aud_grid.py:94-121 build_tensor, :172-188 extract_window): decoded
+RGB frames go to the device as uint8 once and one kernel produces the normalised (B, 1, T, 112, 112) volume, with
+the crop, Pillow-exact resize, flip, grayscale, normalisation, random erasing and zero padding fused.  The random
+draws (flip, erase position, window start) stay on the host, like the reference's `random` calls."""
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, stream
+
+CROP = (59, 95, 195, 231)      # left, upper, right, lower (vid_aud_grid.py:99)
+MEAN, STD = 0.4136, 0.1700     # vid_aud_grid.py:108
+_PREC = 22
+
+
+def _coeffs(in_size, out_size):
+    """Pillow's bilinear resampling coefficients (Resample.c precompute_coeffs + normalize_coeffs_8bpc)."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = fs
+    K = int(np.ceil(support)) * 2 + 1
+    xmin = np.zeros(out_size, np.int32)
+    cnt = np.zeros(out_size, np.int32)
+    kk = np.zeros((out_size, K), np.int32)
+    for xx in range(out_size):
+        c = (xx + 0.5) * scale
+        lo = max(int(c - support + 0.5), 0)
+        hi = min(int(c + support + 0.5), in_size)
+        w = np.array([max(0.0, 1.0 - abs((x + lo - c + 0.5) / fs)) for x in range(hi - lo)], np.float64)
+        if w.sum() != 0.0:
+            w = w / w.sum()
+        kk[xx, :hi - lo] = [int(0.5 + v * (1 << _PREC)) for v in w]
+        xmin[xx], cnt[xx] = lo, hi - lo
+    return xmin, cnt, kk
+
+
+class VideoTransform:
+    """build_tensor for a batch: frames (B, Tin, H0, W0, 3) uint8 on the device -> (B, 1, max_t, 112, 112) float32."""
+
+    def __init__(self, device, crop=CROP, out_size=112, mean=MEAN, std=STD, erase_size=56):
+        self.crop, self.out, self.mean, self.std, self.erase_size = crop, out_size, mean, std, erase_size
+        l, u, r, lo = crop
+        xs = _coeffs(r - l, out_size)
+        ys = _coeffs(lo - u, out_size)
+        self.K = max(xs[2].shape[1], ys[2].shape[1])
+
+        def dev(t):
+            return torch.from_numpy(np.ascontiguousarray(t)).to(device)
+
+        def padk(k):
+            o = np.zeros((k.shape[0], self.K), np.int32)
+            o[:, :k.shape[1]] = k
+            return o
+        self.tabs = [dev(xs[0]), dev(xs[1]), dev(padk(xs[2])), dev(ys[0]), dev(ys[1]), dev(padk(ys[2]))]
+        self.device = device
+
+    def __call__(self, frames, lens, max_t, flip=None, erase=None, start=None):
+        """lens: frames per clip; flip: (B,) bools or None; erase: (B, 2) ints (x_s, y_s) or None; start: (B,) first
+        frame of each clip's window (extract_window) or None."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous() and frames.shape[-1] == 3
+        B, Tin, H0, W0, _ = frames.shape
+        l, u, r, lo = self.crop
+        assert r <= W0 and lo <= H0
+
+        def ints(v, shape):
+            if v is None:
+                return None
+            t = torch.as_tensor(np.asarray(v), dtype=torch.int32).reshape(shape).contiguous()
+            return t.to(self.device)
+        lens_t, start_t, erase_t = ints(lens, (B,)), ints(start, (B,)), ints(erase, (B, 2))
+        flip_t = None if flip is None else torch.as_tensor(np.asarray(flip), dtype=torch.uint8).reshape(B).to(self.device)
+        hi = np.asarray(lens) + (0 if start is None else np.asarray(start))
+        assert int(hi.max()) <= Tin and int(np.asarray(lens).max()) <= max_t
+        out = torch.empty((B, 1, max_t, self.out, self.out), device=self.device, dtype=torch.float32)
+        p = lambda t: None if t is None else t.data_ptr()
+        check(_lib.lib().vca_build_video_f32(B, Tin, max_t, H0, W0, self.out, self.out, self.K, l, u, self.mean,
+                                             self.std, frames.data_ptr(), *[t.data_ptr() for t in self.tabs],
+                                             p(start_t), p(lens_t), p(flip_t), p(erase_t), self.erase_size,
+                                             out.data_ptr(), stream()), 'build_video')
+        return out
+
+
+def draw_augmentations(batch, augment):
+    """The reference's host-side draws: StatefulRandomHorizontalFlip(0.5) per clip (vid_aud_grid.py:96) and the erase
+    box start x_s, y_s ~ randint(-10, 66) (vid_aud_grid.py:116)."""
+    if not augment:
+        return None, None
+    flip = [random.random() < 0.5 for _ in range(batch)]
+    erase = [[random.randint(-10, 66), random.randint(-10, 66)] for _ in range(batch)]
+    return flip, erase
+
+
+def draw_window(num_frames, window_size):
+    """extract_window's start frame (vid_aud_grid.py:176) and the matching mel start / length for 25 fps, 16 kHz, hop 160."""
+    st = random.randint(0, num_frames - window_size)
+    vid_2_aud = 16000 / 25 / 160
+    return st, int(st * vid_2_aud), int(window_size * vid_2_aud)
