@@ -129,7 +129,73 @@ __global__ __launch_bounds__(THR) void mel_down_kernel(int N, int H, int W, int 
   }
 }
 
+// dst[c] += sum_p x[p][c]: the bias gradient of a convolution / linear layer from its output gradient, added
+// straight into the parameter's gradient.  Two kernels and no atomics: up to 256 workgroups each reduce a strided
+// share of the rows into partial[g][C] (float4 columns, rows folded through LDS), then one thread per column sums
+// the partials.
+__global__ __launch_bounds__(THR) void colsum_partial_kernel(int P, int C, const float* __restrict__ x,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[THR * 4];
+  const int C4 = C >> 2;
+  for (int c0 = 0; c0 < C4; c0 += THR) {
+    const int TX = min(C4 - c0, THR), TY = THR / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const bool active = ty < TY;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int col = (c0 + tx) * 4;
+    if (active)
+      for (int r = blockIdx.x * TY + ty; r < P; r += gridDim.x * TY) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + col);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    *reinterpret_cast<float4*>(&red[threadIdx.x * 4]) = s;
+    __syncthreads();
+    if (active && ty == 0) {
+      for (int j = 1; j < TY; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(&red[(j * TX + tx) * 4]);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+      *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C + col) = s;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(THR) void colsum_fold_add_kernel(int G, int C, const float* __restrict__ partial,
+                                                              float* __restrict__ dst) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float t = 0.f;
+  if (c < C)
+    for (int g = rl; g < G; g += 8) t += partial[(size_t)g * C + c];
+  red[rl][cl] = t;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += red[j][cl];
+    dst[c] += t;
+  }
+}
+
 }  // namespace
+
+extern "C" int vca_colsum_groups(int P, int C) {
+  if (P <= 0 || C <= 0 || (C & 3)) return -22;
+  const int C4 = C / 4, TX = C4 < THR ? C4 : THR, TY = THR / TX;
+  int g = (P + TY * 4 - 1) / (TY * 4);      // at least 4 rows per thread
+  if (g > 256) g = 256;
+  return g < 1 ? 1 : g;
+}
+
+extern "C" int vca_colsum_add_f32(int P, int C, const float* x, float* partial, float* dst, void* stream) {
+  VCA_CHECK_ARG(P > 0 && C > 0 && (C % 4) == 0 && x && partial && dst);
+  const int g = vca_colsum_groups(P, C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
+  hipLaunchKernelGGL(colsum_fold_add_kernel, dim3((C + 31) / 32), dim3(THR), 0, (hipStream_t)stream, g, C, partial,
+                     dst);
+  return vca_launch_status();
+}
 
 extern "C" int vca_concat2_f32(int N, int H, int W, int C1, int C2, const float* x1, long long s1n, long long s1h,
                                long long s1w, const float* x2, long long s2n, long long s2h, long long s2w, float* y,

@@ -197,6 +197,19 @@ def _grad_sink(w):
     return None
 
 
+def _bias_grad(gy, bias_param, cout):
+    """Gradient of a bias from the output gradient gy (..., cout): added into the parameter's flat gradient when the
+    step asked for in-place accumulation (returns None), otherwise returned as a fresh tensor."""
+    if cout % 4:
+        return gy.reshape(-1, cout).sum(0)
+    sink = _grad_sink(bias_param) if bias_param is not None else None
+    gb = sink if sink is not None else torch.zeros((cout,), device=gy.device, dtype=torch.float32)
+    P = gy.numel() // cout
+    part = torch.empty((_lib.lib().vca_colsum_groups(P, cout), cout), device=gy.device, dtype=torch.float32)
+    check(_lib.lib().vca_colsum_add_f32(P, cout, ptr(gy), ptr(part), ptr(gb), stream()), 'colsum_add')
+    return None if sink is not None else gb
+
+
 def _conv_wgrad_raw(x, gy, cfg, sink=None):
     """Weight gradient in the parameter's layout; with `sink` (a contiguous tensor of that layout) it is added to
     sink and None is returned."""
@@ -232,6 +245,7 @@ class ConvStatsFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, cfg):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, w)
         stats = torch.zeros((2, cfg.cout), device=x.device, dtype=torch.float32)
         y = _conv_fwd_raw(_c(x), w, bias, cfg, stats)
@@ -246,7 +260,7 @@ class ConvStatsFn(torch.autograd.Function):
         gy = _c(gy)
         gx = _conv_dgrad_raw(gy, w, cfg) if ctx.needs_input_grad[0] else None
         gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
-        gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = _bias_grad(gy, ctx.bias_ref, cfg.cout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
 
@@ -255,6 +269,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, cfg):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, w)
         return _conv_fwd_raw(_c(x), w, bias, cfg)
 
@@ -270,7 +285,9 @@ class ConvFn(torch.autograd.Function):
             sink = _grad_sink(w)
             gw = ConvWgradFn.apply(x, gy, cfg) if sink is None else _conv_wgrad_raw(_c(x), gy, cfg, sink)
         _exact_bwd[0] = False
-        gb = gy.reshape(-1, cfg.cout).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.reshape(-1, cfg.cout).sum(0) if torch.is_grad_enabled() else _bias_grad(gy, ctx.bias_ref, cfg.cout)
         return gx, gw, gb, None
 
 
