@@ -113,7 +113,12 @@ def main():
     assert world == args.gpus, (world, args.gpus)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('VCA_FORCE_EXCHANGE') == '1'   # the latter: one-rank RCCL rehearsal
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
 
     import vcagan_amd  # noqa: F401
@@ -123,7 +128,7 @@ def main():
     models = train_step.build_models(device=device)
     for k in models:
         models[k].train()
-    if world > 1:                      # identical replicas: broadcast rank 0's initialisation
+    if use_dist:                       # identical replicas: broadcast rank 0's initialisation
         for k in sorted(models):
             for t in list(models[k].parameters()) + list(models[k].buffers()):
                 dist.broadcast(t.data, 0)
@@ -135,11 +140,14 @@ def main():
     if not args.no_graph:
         try:
             graphed = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'],
-                                             data['noise'])
+                                             data['noise'],
+                                             segmented=True if os.environ.get('VCA_BENCH_SEGMENTED') == '1' else None)
         except Exception as e:       # capture not possible on this stack: fall back to eager launches
             print('graph capture failed, running eagerly: %r' % (e,), file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+
+    trace_loss = os.environ.get('VCA_BENCH_TRACE_LOSS')    # debugging aid: '1' prints the losses, 'sync' only syncs
 
     def run(n):
         out = None
@@ -148,22 +156,35 @@ def main():
                 out = graphed(data['mel'], data['spec'], data['vid'], None, data['noise'])
             else:
                 out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise=data['noise'])
+            if trace_loss == 'sync':
+                torch.cuda.synchronize()
+            elif trace_loss:
+                print('loss trace: ' + ' '.join('%s %.6f' % (k, float(v)) for k, v in sorted(out.items())
+                                                if torch.is_tensor(v) and v.numel() == 1), file=sys.stderr)
         return out
 
     run(args.warmup)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if os.environ.get('VCA_BENCH_CHECK') == '1':
+        for n, m in models.items():
+            print('check', n, 'params finite', all(bool(torch.isfinite(p).all()) for p in m.parameters()),
+                  'grads finite', all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None),
+                  file=sys.stderr)
+        for k, v in graphed.static.items():
+            print('check static', k, bool(torch.isfinite(v.float()).all()), file=sys.stderr)
     t0 = time.perf_counter()
     out = run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    print('final: gen %.6f dis %.6f' % (float(out['gen_loss']), float(out['dis_loss'])), file=sys.stderr)
     assert torch.isfinite(out['gen_loss']).item() and torch.isfinite(out['dis_loss']).item()
 
     if rank == 0:
@@ -201,7 +222,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -210,7 +210,7 @@ int vca_concat2_f32(int N, int H, int W, int C1, int C2, const float* x1, long l
                     const float* x2, long long s2n, long long s2h, long long s2w, float* y, void* stream);
 int vca_concat2_bwd_f32(int N, int H, int W, int C, int c0, int Cs, const float* gy, long long sn, long long sh,
                         long long sw, int accumulate, float* gx, void* stream);
-/* dst[c] += sum_p x[p][c] (C % 4 == 0): bias gradient of nn.Conv*d / nn.Linear from the output gradient, accumulated
+/* dst[c] += sum_p x[p][c]: bias gradient of nn.Conv*d / nn.Linear from the output gradient, accumulated
  * into the parameter's gradient (what autograd's sum + AccumulateGrad do for the generator.py / visual_front.py
  * biases).  partial is scratch of vca_colsum_groups(P, C) * C floats (need not be initialised). */
 int vca_colsum_groups(int P, int C);

@@ -147,9 +147,43 @@ def test_graph_replay_matches_eager():
             assert len(gs.graphs) == (3 if mode == 'segmented' else 1)
             for _ in range(2):
                 res = gs(b['mel'], b['spec'], b['vid'], None, b['noise'])
+                float(res['gen_loss'])          # what a training loop that logs its losses does between replays
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         out[mode] = {k: float(res[k]) for k in ('dis_loss', 'gen_loss', 'recon_loss', 'sync_loss')}
         assert opts[0].t_dev.item() == 4 and opts[1].t_dev.item() == 4
     for mode in ('graph', 'segmented'):
         for k in out['eager']:
             assert abs(out['eager'][k] - out[mode][k]) <= 3e-2 * abs(out['eager'][k]), (mode, k, out)
+
+
+@gpu
+def test_graph_replay_is_stable_under_host_reads():
+    """Replays of a captured forward pass give the same result whatever the host does between them.  The
+    split-reduction convolutions (few output tiles, deep reduction: the discriminators' heads) accumulate into a
+    zero-filled output; with that fill issued as hipMemsetAsync the graph held memset nodes, and a device-to-host
+    read plus a device synchronisation between two replays made later replays accumulate into stale values."""
+    from vcagan_amd import ops
+    ops.set_precision('bf16x3')
+    m = _models(301, True)
+    dis = m['dis3']
+    g = torch.Generator(device='cpu').manual_seed(7)
+    mel = (torch.rand(32, 1, 80, 300, generator=g) * 2 - 1).cuda()
+    sent = torch.randn(32, 512, 75, generator=g).cuda()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eager = [o.clone() for o in dis(mel, sent, 75)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = dis(mel, sent, 75)
+    for i in range(4):
+        graph.replay()
+        outs[0].flatten()[0].item()
+        torch.cuda.synchronize()
+        for a, b in zip(eager, outs):
+            assert torch.isfinite(b).all(), i
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-6, (i, float((a - b).abs().max()))

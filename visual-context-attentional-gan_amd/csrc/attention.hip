@@ -296,9 +296,8 @@ extern "C" int vca_attention_bwd_f32(int B, int Tq, int S, int D, const float* d
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dk, 0, (size_t)B * S * D * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(dv, 0, (size_t)B * S * D * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  vca_zero_async(dk, (size_t)B * S * D, s);
+  vca_zero_async(dv, (size_t)B * S * D, s);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((Tq + QT - 1) / QT, B), dim3(256), lds_bytes(S, true), s, Tq, S, dctx, q, k,
                      v, probs, scale, dq, dk, dv);
   return vca_launch_status();

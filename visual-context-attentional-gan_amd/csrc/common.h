@@ -18,6 +18,29 @@ static inline int vca_launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// Zero-fill of a float buffer as an ordinary kernel.  Used instead of hipMemsetAsync in front of kernels that
+// accumulate into the buffer with atomics: inside a captured graph a memset becomes a memset node, which the
+// runtime executes on its own path, and replays were observed to start the accumulating kernel before the fill had
+// landed (results changed with unrelated host activity between replays).  A kernel node is ordered like any other.
+static __global__ __launch_bounds__(256) void vca_zero_kernel(float* p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+  }
+}
+
+static inline void vca_zero_async(float* p, size_t n, hipStream_t s) {
+  size_t g = (n / 4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(vca_zero_kernel, dim3((unsigned)g), dim3(256), 0, s, p, n);
+}
+
 // Activation codes shared by the conv prologue and the pointwise kernels.
 enum { VCA_ACT_NONE = 0, VCA_ACT_LEAKY = 1, VCA_ACT_PRELU = 2, VCA_ACT_RELU = 3, VCA_ACT_TANH = 4 };
 

@@ -935,9 +935,7 @@ int launch_halo(HArgs a, int gx, int gy, size_t lds, hipStream_t s) {
     if (ks > a.nchunk / 2) ks = a.nchunk / 2;
     if (ks > 1) {
       a.ksplit = ks;
-      const size_t bytes = (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout * sizeof(float);
-      hipError_t e = hipMemsetAsync(a.y, 0, bytes, s);
-      if (e != hipSuccess) return (int)e;
+      vca_zero_async(a.y, (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout, s);
     }
   }
   hipLaunchKernelGGL(kern, dim3(gx, gy, a.ksplit), dim3(256), lds, s, a);

@@ -133,29 +133,37 @@ __global__ __launch_bounds__(THR) void mel_down_kernel(int N, int H, int W, int 
 // straight into the parameter's gradient.  Two kernels and no atomics: up to 256 workgroups each reduce a strided
 // share of the rows into partial[g][C] (float4 columns, rows folded through LDS), then one thread per column sums
 // the partials.
+template <int VEC>
 __global__ __launch_bounds__(THR) void colsum_partial_kernel(int P, int C, const float* __restrict__ x,
                                                              float* __restrict__ partial) {
-  __shared__ float red[THR * 4];
-  const int C4 = C >> 2;
-  for (int c0 = 0; c0 < C4; c0 += THR) {
-    const int TX = min(C4 - c0, THR), TY = THR / TX;
+  __shared__ float red[THR * VEC];
+  const int CV = C / VEC;                      // VEC = 4 when the row length allows 16-byte loads, else 1
+  for (int c0 = 0; c0 < CV; c0 += THR) {
+    const int TX = min(CV - c0, THR), TY = THR / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const bool active = ty < TY;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int col = (c0 + tx) * 4;
+    float s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+    const int col = (c0 + tx) * VEC;
     if (active)
       for (int r = blockIdx.x * TY + ty; r < P; r += gridDim.x * TY) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + col);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if constexpr (VEC == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + col);
+          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        } else {
+          s[0] += x[(size_t)r * C + col];
+        }
       }
-    *reinterpret_cast<float4*>(&red[threadIdx.x * 4]) = s;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[threadIdx.x * VEC + k] = s[k];
     __syncthreads();
     if (active && ty == 0) {
-      for (int j = 1; j < TY; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(&red[(j * TX + tx) * 4]);
-        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-      }
-      *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C + col) = s;
+      for (int j = 1; j < TY; ++j)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s[k] += red[(j * TX + tx) * VEC + k];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) partial[(size_t)blockIdx.x * C + col + k] = s[k];
     }
     __syncthreads();
   }
@@ -181,17 +189,20 @@ __global__ __launch_bounds__(THR) void colsum_fold_add_kernel(int G, int C, cons
 }  // namespace
 
 extern "C" int vca_colsum_groups(int P, int C) {
-  if (P <= 0 || C <= 0 || (C & 3)) return -22;
-  const int C4 = C / 4, TX = C4 < THR ? C4 : THR, TY = THR / TX;
+  if (P <= 0 || C <= 0) return -22;
+  const int C4 = (C & 3) ? C : C / 4, TX = C4 < THR ? C4 : THR, TY = THR / TX;
   int g = (P + TY * 4 - 1) / (TY * 4);      // at least 4 rows per thread
   if (g > 256) g = 256;
   return g < 1 ? 1 : g;
 }
 
 extern "C" int vca_colsum_add_f32(int P, int C, const float* x, float* partial, float* dst, void* stream) {
-  VCA_CHECK_ARG(P > 0 && C > 0 && (C % 4) == 0 && x && partial && dst);
+  VCA_CHECK_ARG(P > 0 && C > 0 && x && partial && dst);
   const int g = vca_colsum_groups(P, C);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
   hipLaunchKernelGGL(colsum_fold_add_kernel, dim3((C + 31) / 32), dim3(THR), 0, (hipStream_t)stream, g, C, partial,
                      dst);
   return vca_launch_status();

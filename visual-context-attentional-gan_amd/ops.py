@@ -190,6 +190,23 @@ class direct_param_grad:
         _direct_grad[0] = self.prev
 
 
+_inputs_only = [False]  # set by input_grads_only()
+
+
+class input_grads_only:
+    """While active, convolution / linear backward passes skip the weight and bias gradients.  For
+    torch.autograd.grad(outputs, inputs=<activations>) calls such as the R1 penalty (train.py:189-194): a Python
+    autograd Function only knows which of its inputs require grad, not which gradients the caller asked for, so
+    it would compute every parameter gradient and autograd would drop them."""
+
+    def __enter__(self):
+        self.prev = _inputs_only[0]
+        _inputs_only[0] = True
+
+    def __exit__(self, *exc):
+        _inputs_only[0] = self.prev
+
+
 def _grad_sink(w):
     if (_direct_grad[0] and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.grad is not None
             and w.grad.is_contiguous()):
@@ -200,14 +217,25 @@ def _grad_sink(w):
 def _bias_grad(gy, bias_param, cout):
     """Gradient of a bias from the output gradient gy (..., cout): added into the parameter's flat gradient when the
     step asked for in-place accumulation (returns None), otherwise returned as a fresh tensor."""
-    if cout % 4:
-        return gy.reshape(-1, cout).sum(0)
     sink = _grad_sink(bias_param) if bias_param is not None else None
     gb = sink if sink is not None else torch.zeros((cout,), device=gy.device, dtype=torch.float32)
-    P = gy.numel() // cout
-    part = torch.empty((_lib.lib().vca_colsum_groups(P, cout), cout), device=gy.device, dtype=torch.float32)
-    check(_lib.lib().vca_colsum_add_f32(P, cout, ptr(gy), ptr(part), ptr(gb), stream()), 'colsum_add')
+    _colsum_add(gy, cout, gb)
     return None if sink is not None else gb
+
+
+def _colsum_add(x, c, dst):
+    """dst[c] += column sums of the contiguous x viewed as (-1, c).  Used instead of torch's sum(0): its multi-block
+    reduction zeroes a semaphore buffer with a memset, and memset nodes are not reliable in replayed HIP graphs."""
+    x = x.contiguous()
+    P = x.numel() // c
+    part = torch.empty((_lib.lib().vca_colsum_groups(P, c), c), device=x.device, dtype=torch.float32)
+    check(_lib.lib().vca_colsum_add_f32(P, c, ptr(x), ptr(part), ptr(dst), stream()), 'colsum_add')
+    return dst
+
+
+def colsum(x, c):
+    """Column sums of x viewed as (-1, c), as a fresh (c,) tensor (no autograd)."""
+    return _colsum_add(x, c, torch.zeros((c,), device=x.device, dtype=torch.float32))
 
 
 def _conv_wgrad_raw(x, gy, cfg, sink=None):
@@ -281,12 +309,12 @@ class ConvFn(torch.autograd.Function):
         _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, w, cfg) if ctx.needs_input_grad[0] else None
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _inputs_only[0]:
             sink = _grad_sink(w)
             gw = ConvWgradFn.apply(x, gy, cfg) if sink is None else _conv_wgrad_raw(_c(x), gy, cfg, sink)
         _exact_bwd[0] = False
         gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _inputs_only[0]:
             gb = gy.reshape(-1, cfg.cout).sum(0) if torch.is_grad_enabled() else _bias_grad(gy, ctx.bias_ref, cfg.cout)
         return gx, gw, gb, None
 
@@ -1009,8 +1037,8 @@ class GruLayerFn(torch.autograd.Function):
         for d in range(2):
             w_ih = wts[4 * d]
             gi2, gh2 = d_gi[d].view(T * B, 3 * H), d_gh[d].view(T * B, 3 * H)
-            grads += [_gemm_tn(x2, gi2, w_ih), _gemm_tn(hprev[d].view(T * B, H), gh2, w_hh[d]), gi2.sum(0),
-                      gh2.sum(0)]
+            grads += [_gemm_tn(x2, gi2, w_ih), _gemm_tn(hprev[d].view(T * B, H), gh2, w_hh[d]), colsum(gi2, 3 * H),
+                      colsum(gh2, 3 * H)]
             if ctx.needs_input_grad[0]:
                 part = _gemm_nn(gi2, w_ih)
                 dx = part if dx is None else dx + part

@@ -101,7 +101,8 @@ class GanStep:
         sync_loss = m['s_dis'](phon_d, reals[2]).mean()
         grad_p = []
         for (u, _), r in zip(real_lo, reals):
-            gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
+            with ops.input_grads_only():
+                gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
             grad_p.append(gr.reshape(gr.size(0), -1).pow(2).sum(1).mean())
         fake_lo = [d(g.detach(), sd, T) for d, g in zip(dis, (g1, g2, g3))]
         real_loss = (sum(G.gan_loss(u, True) for u, _ in real_lo)
@@ -171,7 +172,7 @@ class GraphedStep:
         dev = mel.device
         self.static = dict(mel=mel.clone(), spec=spec.clone(), vid=vid.clone(), noise=noise.clone(),
                            vid_len=torch.as_tensor([int(l) for l in vid_len], device=dev))
-        self.segmented = (step.d_exchange.world > 1) if segmented is None else bool(segmented)
+        self.segmented = step.d_exchange.active if segmented is None else bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -186,7 +187,7 @@ class GraphedStep:
                 self.out = self._run()
         else:
             # Other threads (the process group's watchdog) may touch the device while a phase is being captured.
-            mode = 'thread_local' if step.d_exchange.world > 1 else 'global'
+            mode = 'thread_local' if step.d_exchange.active else 'global'
             pool = torch.cuda.graph_pool_handle()
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
