@@ -210,6 +210,15 @@ int vca_concat2_f32(int N, int H, int W, int C1, int C2, const float* x1, long l
                     const float* x2, long long s2n, long long s2h, long long s2w, float* y, void* stream);
 int vca_concat2_bwd_f32(int N, int H, int W, int C, int c0, int Cs, const float* gy, long long sn, long long sh,
                         long long sw, int accumulate, float* gx, void* stream);
+/* Decoder input without the tiled copy (generator.py:249-250 repeats the phoneme features over the 20 frequency rows
+ * and concatenates noise; decode[0] then runs BN, a 5x5 and a 1x1 convolution over it, generator.py:94-131).  For the
+ * repeated channels a KxK convolution is K 1xK convolutions of the single row (kernel row kh stacked in the output
+ * channels, p: (B, W, K*C)); output row h sums the kernel rows that stay inside the map:
+ *   expand: y[b][h][w][c] = base[b][h][w][c] (optional) + sum_{0 <= h+kh-pad < H} p[b][w][kh*C + c]
+ *   reduce: gp[b][w][kh*C + c] = sum_{0 <= h+kh-pad < H} gy[b][h][w][c]   (the adjoint, for the backward pass) */
+int vca_hband_expand_f32(int B, int H, int W, int C, int K, int pad, const float* p, const float* base, float* y,
+                         void* stream);
+int vca_hband_reduce_f32(int B, int H, int W, int C, int K, int pad, const float* gy, float* gp, void* stream);
 /* dst[c] += sum_p x[p][c]: bias gradient of nn.Conv*d / nn.Linear from the output gradient, accumulated
  * into the parameter's gradient (what autograd's sum + AccumulateGrad do for the generator.py / visual_front.py
  * biases).  partial is scratch of vca_colsum_groups(P, C) * C floats (need not be initialised). */

@@ -82,3 +82,73 @@ def test_mel_pyramid_matches_interpolate(factor):
     ref = F.interpolate(mel, scale_factor=1.0 / factor, mode='bilinear', align_corners=False)
     out = ops.mel_down(mel.cuda(), factor)
     assert out.shape == ref.shape and torch.allclose(out.cpu(), ref, atol=1e-6)
+
+
+@gpu
+def test_hband_expand_matches_rowwise_sum():
+    """y[b,h,w,c] = base + sum_{0 <= h+kh-pad < H} p[b,w,kh*C+c] and its adjoint, vs a torch loop."""
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (B, H, W, C, K, pad) in [(2, 20, 7, 8, 5, 2), (3, 4, 5, 12, 1, 0), (1, 3, 6, 4, 5, 2)]:
+        p0 = torch.randn(B, W, K * C, generator=g)
+        base0 = torch.randn(B, H, W, C, generator=g)
+        gy = torch.randn(B, H, W, C, generator=g)
+        pr, br = p0.clone().requires_grad_(True), base0.clone().requires_grad_(True)
+        rows = []
+        for h in range(H):
+            acc = br[:, h]
+            for kh in range(K):
+                if 0 <= h + kh - pad < H:
+                    acc = acc + pr[:, :, kh * C:(kh + 1) * C]
+            rows.append(acc)
+        ref = torch.stack(rows, 1)
+        ref.backward(gy)
+        p, base = p0.cuda().requires_grad_(True), base0.cuda().requires_grad_(True)
+        y = ops.hband_expand(p, H, K, pad, base=base)
+        assert torch.allclose(y.cpu(), ref.detach(), atol=1e-6)
+        y.backward(gy.cuda())
+        assert torch.allclose(p.grad.cpu(), pr.grad, atol=1e-5) and torch.allclose(base.grad.cpu(), br.grad, atol=1e-6)
+        y2 = ops.hband_expand(p0.cuda(), H, K, pad)
+        assert torch.allclose(y2.cpu(), (ref - br).detach(), atol=1e-5)
+
+
+@gpu
+@pytest.mark.parametrize('train', [True, False])
+def test_tiled_decoder_input_equals_explicit_concat(train):
+    """decode[0] on (phonemes tiled over the 20 rows | noise) computed from the single phoneme row
+    (GenResBlk.forward_tiled) equals the block applied to the explicit concatenation (generator.py:249-251):
+    output, running statistics, input gradient and every parameter gradient.  fp32 kernels, 2e-4 relative."""
+    import copy
+    from vcagan_amd import ops
+    from vcagan_amd.models import generator as G
+    ops.set_precision('fp32')
+    torch.manual_seed(11)
+    blk = G.GenResBlk(64 + 16, 32).cuda().train(train)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.add_(torch.randn_like(prm) * 0.05)
+        blk.norm1.running_var.uniform_(0.5, 2.0)
+        blk.norm1.running_mean.normal_()
+    blk2 = copy.deepcopy(blk)
+    B, H, W = 3, 20, 9
+    x0 = torch.randn(B, W, 64, device='cuda')
+    nz = torch.randn(B, H, W, 16, device='cuda')
+    gy = torch.randn(B, H, W, 32, device='cuda')
+    xa = x0.clone().requires_grad_(True)
+    ya = blk(ops.concat2(xa, nz, B, H, W))
+    ya.backward(gy)
+    xb = x0.clone().requires_grad_(True)
+    yb = blk2.forward_tiled(xb, nz)
+    yb.backward(gy)
+
+    def close(a, b, what):
+        err = float((a - b).detach().abs().max())
+        # 2e-5 absolute floor: conv1.bias feeds a batch-norm, its exact gradient is 0 and both sides hold rounding noise
+        assert err <= 2e-4 * float(a.detach().abs().max()) + 2e-5, (what, err, float(a.detach().abs().max()))
+
+    close(ya, yb, 'output')
+    close(xa.grad, xb.grad, 'input gradient')
+    for (n, pa), (_, pb) in zip(blk.named_parameters(), blk2.named_parameters()):
+        close(pa.grad, pb.grad, n)
+    for (n, ba), (_, bb) in zip(blk.named_buffers(), blk2.named_buffers()):
+        close(ba.float(), bb.float(), n)

@@ -78,6 +78,8 @@ _SIGS = {
     'vca_concat2_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _LL, _LL, _LL, _I, _P, _P], _I),
     'vca_colsum_groups': ([_I, _I], _I),
     'vca_colsum_add_f32': ([_I, _I, _P, _P, _P, _P], _I),
+    'vca_hband_expand_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P], _I),
+    'vca_hband_reduce_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_window_mean_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_window_mean_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_dropout_f32': ([_LL, _P, _F, ctypes.c_ulonglong, _P, _P, _P, _P], _I),

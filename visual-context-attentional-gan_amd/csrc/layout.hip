@@ -186,6 +186,57 @@ __global__ __launch_bounds__(THR) void colsum_fold_add_kernel(int G, int C, cons
   }
 }
 
+
+// A map whose first channels are one feature row repeated over the H axis (the decoder input: phoneme features tiled
+// over the 20 frequency rows, generator.py:249-250) never needs the repeated rows materialised: a KxK convolution of
+// it is, per kernel row kh, a 1xK convolution of the single row, and output row h is the sum of the kernel rows that
+// stay inside the map, 0 <= h + kh - pad < H.
+//   expand:  y[b][h][w][c] = (base ? base[b][h][w][c] : 0) + sum_{kh valid for h} p[b][w][kh*C + c]
+//   reduce:  gp[b][w][kh*C + c] = sum_{h valid for kh} gy[b][h][w][c]          (its adjoint)
+__global__ __launch_bounds__(THR) void hband_expand_kernel(int B, int H, int W, int C, int K, int pad,
+                                                           const float* __restrict__ p,
+                                                           const float* __restrict__ base, float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H), b = (int)(r / H);
+    float4 acc = base ? *reinterpret_cast<const float4*>(base + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* prow = p + ((size_t)b * W + w) * K * C + c;
+    for (int kh = 0; kh < K; ++kh) {
+      const int hs = h + kh - pad;
+      if (hs < 0 || hs >= H) continue;
+      const float4 v = *reinterpret_cast<const float4*>(prow + (size_t)kh * C);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(THR) void hband_reduce_kernel(int B, int H, int W, int C, int K, int pad,
+                                                           const float* __restrict__ gy, float* __restrict__ gp) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * W * K * C4;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int kh = (int)(r % K);
+    r /= K;
+    const int w = (int)(r % W), b = (int)(r / W);
+    // rows h with 0 <= h + kh - pad < H
+    const int h0 = max(0, pad - kh), h1 = min(H, H + pad - kh);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = h0; h < h1; ++h) {
+      const float4 v = *reinterpret_cast<const float4*>(gy + (((size_t)b * H + h) * W + w) * C + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(gp + i * 4) = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int vca_colsum_groups(int P, int C) {
@@ -260,5 +311,21 @@ extern "C" int vca_mel_down_f32(int N, int H, int W, int factor, const float* x,
   VCA_CHECK_ARG(N > 0 && (factor == 2 || factor == 4) && H >= factor && W >= factor && x && y);
   hipLaunchKernelGGL(mel_down_kernel, dim3(grid_for((size_t)N * (H / factor) * (W / factor))), dim3(THR), 0,
                      (hipStream_t)stream, N, H, W, factor, x, y);
+  return vca_launch_status();
+}
+
+extern "C" int vca_hband_expand_f32(int B, int H, int W, int C, int K, int pad, const float* p, const float* base,
+                                    float* y, void* stream) {
+  VCA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && K > 0 && pad >= 0 && pad < K && p && y);
+  hipLaunchKernelGGL(hband_expand_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(THR), 0,
+                     (hipStream_t)stream, B, H, W, C, K, pad, p, base, y);
+  return vca_launch_status();
+}
+
+extern "C" int vca_hband_reduce_f32(int B, int H, int W, int C, int K, int pad, const float* gy, float* gp,
+                                    void* stream) {
+  VCA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && K > 0 && pad >= 0 && pad < K && gy && gp);
+  hipLaunchKernelGGL(hband_reduce_kernel, dim3(grid_for((size_t)B * W * K * (C / 4))), dim3(THR), 0,
+                     (hipStream_t)stream, B, H, W, C, K, pad, gy, gp);
   return vca_launch_status();
 }

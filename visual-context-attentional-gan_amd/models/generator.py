@@ -14,6 +14,7 @@ from .. import ops
 from .resnet import BasicBlock
 
 _RSQRT2 = 1.0 / math.sqrt(2.0)
+TILED_INPUT = True     # False: build the (B, 20, T, 640) decoder input explicitly (the reference's formulation)
 
 
 def _conv(x, m, ups=0, **kw):
@@ -84,6 +85,29 @@ class GenResBlk(nn.Module):
         else:
             assert not ups
             s = x
+        return ops.add_scale(r, s, _RSQRT2)
+
+    def forward_tiled(self, x, nz):
+        """The block applied to cat([x tiled over the rows of nz, nz], channels) (generator.py:249-251) without
+        forming the tiled map.  x: (B, W, C1), one row per clip; nz: (B, H, W, C2).  For the tiled channels every
+        per-channel step (batch-norm, activation) acts on the single row, the 5x5 convolution is five 1x5
+        convolutions of that row (kernel rows stacked in the output channels) summed per output row over the kernel
+        rows that stay inside the map, and the 1x1 shortcut is a linear layer repeated over the rows."""
+        assert self.learned_sc and not self.upsample
+        B, H, W, _ = nz.shape
+        C1 = x.shape[-1]
+        co = self.conv1.out_channels
+        ax, an = ops.bn_act_parts([(x, H), (nz, 1)], self.norm1, ops.LEAKY)
+        w1 = self.conv1.weight
+        kh, kw = w1.shape[2], w1.shape[3]
+        w_rows = w1[:, :C1].permute(2, 0, 1, 3).reshape(kh * co, C1, 1, kw)
+        p = ops.conv2d(ax.view(B, 1, W, C1), w_rows, None, 1, (0, kw // 2))           # (B, 1, W, kh*co)
+        r = ops.conv2d(an, w1[:, C1:].contiguous(), self.conv1.bias, 1, (kh // 2, kw // 2))
+        r = ops.hband_expand(p.view(B, W, kh * co), H, kh, kh // 2, base=r)
+        r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
+        wsc = self.conv1x1.weight
+        s = ops.conv2d(nz, wsc[:, C1:].contiguous(), None, 1, 0)
+        s = ops.hband_expand(ops.linear(x, wsc[:, :C1, 0, 0].contiguous()), H, 1, 0, base=s)
         return ops.add_scale(r, s, _RSQRT2)
 
 
@@ -180,9 +204,12 @@ class Decoder(nn.Module):
         len = ops.as_lens(len, x.device)
         if noise is None:
             noise = torch.randn([B, 128, 20, T])
-        noise = noise.to(x.device).permute(0, 2, 3, 1)
-        h = ops.concat2(x, noise, B, 20, T)                               # (B, 20, T, 640): phonemes tiled | noise
-        for block in self.decode:
+        noise = noise.to(x.device).permute(0, 2, 3, 1)                   # (B, 20, T, 128) channels-last view
+        if TILED_INPUT:
+            h = self.decode[0].forward_tiled(x, noise.contiguous())      # phonemes tiled | noise, never materialised
+        else:
+            h = self.decode[0](ops.concat2(x, noise, B, 20, T))          # (B, 20, T, 640)
+        for block in list(self.decode)[1:]:
             h = block(h)
         for block in self.g1:
             h = block(h)

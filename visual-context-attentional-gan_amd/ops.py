@@ -548,6 +548,85 @@ def _bn_coef(x, bn, stats=None):
     return coef, False
 
 
+def bn_act_parts(parts, bn, act=None):
+    """Batch-norm + activation of a tensor that is only given by its channel groups: parts = [(x_i, rep_i), ...],
+    x_i channels-last holding the channels [c_i, c_i + C_i) of the normalised tensor, each row of x_i standing for
+    rep_i identical rows of it (rows * rep is the same for all parts).  Returns the activated parts in their own
+    shapes.  Statistics, running statistics and gradients are those of batch-norm over the assembled tensor."""
+    code, slope, alpha = _act_code(act)
+    assert alpha is None
+    dev = parts[0][0].device
+    C = sum(x.shape[-1] for x, _ in parts)
+    n = _pc(parts[0][0])[0] * parts[0][1]
+    L = _lib.lib()
+    coef = torch.empty((4, C), device=dev, dtype=torch.float32)
+    g, b = bn.weight, bn.bias
+    if bn.training or bn.running_mean is None:
+        sums, pivots = [], []
+        for x, rep in parts:
+            P, Ci = _pc(x)
+            assert P * rep == n, (P, rep, n)
+            xs = _c(x.detach())
+            sm = torch.zeros((16, 2, Ci), device=dev, dtype=torch.float32)   # VCA_BN_SLOTS partial buffers
+            check(L.vca_colstats_f32(P, Ci, ptr(xs), ptr(sm), stream()), 'colstats')
+            sums.append(sm[0] * float(rep) if rep != 1 else sm[0])
+            pivots.append(xs.reshape(P, Ci)[0])
+        sums, pivot = torch.cat(sums, 1).contiguous(), torch.cat(pivots).contiguous()
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        check(L.vca_bn_finalize_f32(C, float(n), ptr(sums), ptr(pivot), ptr(g.detach()), ptr(b.detach()), bn.eps, mom,
+                                    ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                    ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
+        if track:
+            bn.num_batches_tracked += 1
+        train = True
+    else:
+        check(L.vca_bn_eval_coeff_f32(C, ptr(bn.running_mean), ptr(bn.running_var), ptr(g.detach()), ptr(b.detach()),
+                                      bn.eps, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()),
+              'bn_eval_coeff')
+        train = False
+    outs, c0 = [], 0
+    for x, rep in parts:
+        Ci = x.shape[-1]
+        # A repeated row receives the sum of its copies' gradients, and the batch-norm correction terms summed
+        # over the rep copies are rep/n = 1/rows of x: the ordinary backward over the rows of x is exact.
+        outs.append(BnActFn.apply(x, g[c0:c0 + Ci], b[c0:c0 + Ci], None, None, coef[:, c0:c0 + Ci], code, slope, 1.0,
+                                  train))
+        c0 += Ci
+    return outs
+
+
+class HBandExpandFn(torch.autograd.Function):
+    """y[b,h,w,c] = base[b,h,w,c] + sum over kernel rows kh with 0 <= h+kh-pad < H of p[b,w,kh*C+c]: assembles the
+    KxK convolution of a map that repeats one row over H from the K row-wise 1xK convolutions of that row."""
+
+    @staticmethod
+    def forward(ctx, p, base, H, K, pad):
+        p = _c(p)
+        B, W, KC = p.shape
+        C = KC // K
+        base = _c(base) if base is not None else None
+        y = torch.empty((B, H, W, C), device=p.device, dtype=torch.float32)
+        check(_lib.lib().vca_hband_expand_f32(B, H, W, C, K, pad, ptr(p), ptr(base), ptr(y), stream()), 'hband_expand')
+        ctx.cfg = (B, H, W, C, K, pad)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        B, H, W, C, K, pad = ctx.cfg
+        gy = _c(gy)
+        gp = None
+        if ctx.needs_input_grad[0]:
+            gp = torch.empty((B, W, K * C), device=gy.device, dtype=torch.float32)
+            check(_lib.lib().vca_hband_reduce_f32(B, H, W, C, K, pad, ptr(gy), ptr(gp), stream()), 'hband_reduce')
+        return gp, (gy if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def hband_expand(p, H, K=1, pad=0, base=None):
+    return HBandExpandFn.apply(p, base, H, K, pad)
+
+
 def bn_act(x, bn, act=None, residual=None, stats=None):
     """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor."""
     code, slope, alpha = _act_code(act)
