@@ -37,13 +37,14 @@ def synth(b, t, h, device, seed):
 
 
 def roofline_probe(device, dtype):
-    """Time the dominant kernel (the implicit-GEMM convolution) on the step's largest layer, decode.0.conv1
-    (5x5, 640->512 on the 20x75 map of 32 clips), with HIP events on the stream it is launched on."""
+    """Time the dominant kernel (the implicit-GEMM convolution) on the largest layer the step runs, decode.0.conv2
+    (5x5, 512->512 on the 20x75 map of 32 clips; decode.0.conv1 no longer sees the tiled 640-channel input), with
+    HIP events on the stream it is launched on."""
     from vcagan_amd import ops
-    x = torch.randn(B, 20, T, 640, device=device)
-    w = torch.nn.Parameter(torch.randn(512, 640, 5, 5, device=device) * 0.01)
+    x = torch.randn(B, 20, T, 512, device=device)
+    w = torch.nn.Parameter(torch.randn(512, 512, 5, 5, device=device) * 0.01)
     bias = torch.zeros(512, device=device)
-    flops = 2.0 * B * 20 * T * 640 * 25 * 512
+    flops = 2.0 * B * 20 * T * 512 * 25 * 512
     with torch.no_grad():
         for _ in range(2):
             ops.conv2d(x, w, bias, 1, 2)
@@ -61,12 +62,12 @@ def roofline_probe(device, dtype):
     issued = ach * MFMA_PER_PRODUCT[dtype]          # matrix-core work actually issued (3 bf16 MFMAs per product)
     kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else 'conv_bf16_halo_kernel<128,2,2,%d>' % MFMA_PER_PRODUCT[dtype]
     # HBM-side bytes per launch of this kernel on this layer from separate rocprofv3 --pmc passes
-    # (profiles/r1_decode0conv1_pmc_v2.txt): 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE, in KiB.
-    # Algorithmic bytes (input + packed weights + output, each once) are 123 + 33 + 98 = 254 MB; the excess is the
+    # (profiles/r1_decode0conv2_pmc.txt): 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE, in KiB.
+    # Algorithmic bytes (input + packed weights + output, each once) are 98 + 26 + 98 = 222 MB; the excess is the
     # input halo re-read once per 128-channel output block and the weight stream re-read per pixel block, which the
     # 256 MiB Infinity Cache absorbs (the counters sit on the L2's fabric side and include its hits).
-    traffic = (2 * 653092 + 96000) * 1024 if dtype in ('bf16x3', 'mixed') else None
-    return dict(bound='mfma', kernel=kern + ' on decode.0.conv1', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
+    traffic = (2 * 525027 + 96000) * 1024 if dtype in ('bf16x3', 'mixed') else None
+    return dict(bound='mfma', kernel=kern + ' on decode.0.conv2', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
                 issued_frac=round(issued / peak, 4), traffic=traffic, launch_ms=round(dt * 1e3, 3),
                 flops_per_launch=flops)

@@ -152,3 +152,31 @@ def test_tiled_decoder_input_equals_explicit_concat(train):
         close(pa.grad, pb.grad, n)
     for (n, ba), (_, bb) in zip(blk.named_buffers(), blk2.named_buffers()):
         close(ba.float(), bb.float(), n)
+
+
+@gpu
+def test_untiled_condition_head_equals_explicit_concat():
+    """Discriminator.cond[1] on (features | sentence vector tiled over the 5 x T/4 map) computed from the vector
+    (Discriminator._cond_conv) equals the convolution of the explicit concatenation (generator.py:312-315): logits,
+    input gradient, every parameter gradient.  fp32 kernels."""
+    from vcagan_amd import ops
+    from vcagan_amd.models import generator as G
+    ops.set_precision('fp32')
+    torch.manual_seed(12)
+    dis = G.Discriminator(phase='1').cuda()
+    mel = torch.randn(3, 1, 20, 24, device='cuda')
+    c = torch.randn(3, 512, 24, device='cuda')
+    res = {}
+    for tiled in (False, True):
+        G.TILED_INPUT = tiled
+        try:
+            dis.zero_grad()
+            m = mel.clone().requires_grad_(True)
+            u, o = dis(m, c, 24)
+            (u.sum() + (o * torch.arange(1, 4, device='cuda').view(3, 1)).sum()).backward()
+            res[tiled] = [u.detach(), o.detach(), m.grad] + [p.grad.clone() for p in dis.parameters()]
+        finally:
+            G.TILED_INPUT = True
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        err = float((a - b).abs().max())
+        assert err <= 2e-4 * float(a.abs().max()) + 1e-6, (i, err, float(a.abs().max()))

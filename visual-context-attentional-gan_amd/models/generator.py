@@ -243,6 +243,21 @@ class Discriminator(nn.Module):
                                   nn.Conv2d(dim_out, dim_out, 5, 1, 0), nn.LeakyReLU(0.2),
                                   Avgpool(), nn.Linear(dim_out, num_class))
 
+    def _cond_conv(self, ah, av):
+        """cond[1] applied to cat([ah, av tiled over the map], channels) (generator.py:312-315) without forming the
+        tiled channels: a vector repeated over the whole map contributes, per kernel tap, one matrix-vector product
+        (all taps as one linear layer), and an output position sums the taps that stay inside the map, first over
+        the kernel columns for every output column, then over the kernel rows for every output row."""
+        conv = self.cond[1]
+        B, H, W, C = ah.shape
+        co, kh, kw = conv.out_channels, conv.kernel_size[0], conv.kernel_size[1]
+        wc = conv.weight
+        q = ops.linear(av, wc[:, C:].permute(2, 3, 0, 1).reshape(kh * kw * co, av.shape[-1]))   # (B, kh*kw*co)
+        qw = ops.hband_expand(q.view(B * kh, 1, kw * co), W, kw, conv.padding[1])              # (B*kh, W, 1, co)
+        qw = qw.view(B, kh, W, co).permute(0, 2, 1, 3).reshape(B, W, kh * co)
+        o = ops.conv2d(ah, wc[:, :C].contiguous(), conv.bias, 1, tuple(conv.padding))
+        return ops.hband_expand(qw, H, kh, conv.padding[0], base=o)
+
     def forward(self, x, c, vid_max_length):
         """x: (B, 1, F, M) mel; c: (B, 512, T) sentence features.  Returns (B, 1) unconditional and conditional logits."""
         B = x.size(0)
@@ -250,10 +265,14 @@ class Discriminator(nn.Module):
         h = _conv(x.reshape(B, x.size(2), x.size(3), 1), self.main[0])
         for blk in list(self.main)[1:]:
             h = blk(h)
-        u = _conv(ops.leaky(h), self.uncond[1])
+        ah = ops.leaky(h)
+        u = _conv(ah, self.uncond[1])
         u = ops.linear(ops.spatial_mean(ops.leaky(u)), self.uncond[4].weight, self.uncond[4].bias)
         cvec = ops.WindowMeanFn.apply(c.reshape(B * 512, 1, c.size(2), 1), 1, c.size(2)).view(B, 512)   # c.mean(2)
-        o = _conv(ops.leaky(ops.concat2(h, cvec, B, 5, f_len)), self.cond[1])
+        if TILED_INPUT:
+            o = self._cond_conv(ah, ops.leaky(cvec))
+        else:
+            o = _conv(ops.leaky(ops.concat2(h, cvec, B, 5, f_len)), self.cond[1])
         o = _conv(ops.leaky(o), self.cond[3])
         o = ops.linear(ops.spatial_mean(ops.leaky(o)), self.cond[6].weight, self.cond[6].bias)
         return u.view(B, -1), o.view(B, -1)
