@@ -104,6 +104,11 @@ int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src
 int vca_stem_pack_weight(const float* w, void* wpack, void* stream);
 int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, const void* wpack, float* y,
                       float* stats, void* stream);
+/* Patch form of the clip for the stem's weight gradient (visual_front.py:11 backward): xp is
+ * [B][T][OH*OW][64] with channel kh*8+kw = clip[b][t][2*oy+kh-3][2*ox+kw-3] (zero outside the clip and for kh or
+ * kw = 7), over which the 5x7x7 stride-(1,2,2) convolution is a 5-tap convolution along t with 64 input channels,
+ * so that vca_conv_wgrad_bf16 (N=B, H=T, W=OH*OW, KH=5, KW=1, pad_h=2) computes the stem's weight gradient. */
+int vca_stem_patches_f32(int B, int T, int H, int W, const float* x, float* xp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-channel kernels on a channels-last matrix view x[P][C] (C % 4 == 0).

@@ -159,4 +159,5 @@ def test_stem_kernel(shape, prec, tol):
     assert rel_err(stats[0], yl.reshape(-1, 64).sum(0)) < max(tol, 1e-4)
     assert rel_err(stats[1], yl.reshape(-1, 64).pow(2).sum(0)) < max(tol, 1e-4)
     y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().cuda())
-    assert rel_err(wd.grad, wr.grad) < 2e-5
+    # the weight gradient runs at the same matrix-core precision as the forward pass (patch form of the clip)
+    assert rel_err(wd.grad, wr.grad) < (2e-5 if prec == 'bf16x3' else tol)

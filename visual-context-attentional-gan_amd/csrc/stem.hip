@@ -208,3 +208,43 @@ extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const f
                        y, stats, tiles_y, tiles_x, (int)npatch);
   return vca_launch_status();
 }
+
+// Patch form of the clip for the stem's weight gradient: one row of 64 values per output position,
+//   xp[b][t][oy*OW + ox][kh*8 + kw] = clip[b][t][2*oy + kh - 3][2*ox + kw - 3]   (zero outside; kh, kw = 7 unused),
+// over which the 5x7x7 stride-(1,2,2) convolution is a 5-tap convolution along t with 64 input channels.  In that
+// form the weight gradient is one 64x64 tile of 5 taps on the split-bf16 matrix-core kernel instead of 245
+// single-channel taps in fp32.
+__global__ __launch_bounds__(256) void stem_patch_kernel(int BT, int H, int W, int OH, int OW,
+                                                         const float* __restrict__ x, float* __restrict__ xp) {
+  const size_t total = (size_t)BT * OH * OW * 16;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i & 15);                 // kh = q >> 1, kw = (q & 1) * 4 .. +3
+    size_t r = i >> 4;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t img = r / OH;
+    const int kh = q >> 1, kw0 = (q & 1) * 4;
+    const int ys = 2 * oy + kh - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kh < 7 && ys >= 0 && ys < H) {
+      const float* row = x + (img * H + ys) * W;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xs = 2 * ox + kw0 + j - 3;
+        if (kw0 + j < 7 && xs >= 0 && xs < W) v[j] = row[xs];
+      }
+    }
+    *reinterpret_cast<float4*>(xp + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int vca_stem_patches_f32(int B, int T, int H, int W, const float* x, float* xp, void* stream) {
+  VCA_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && x && xp);
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  size_t n = (size_t)B * T * OH * OW * 16, g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(stem_patch_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, B * T, H, W, OH, OW, x,
+                     xp);
+  return vca_launch_status();
+}

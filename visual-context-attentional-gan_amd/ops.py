@@ -437,8 +437,22 @@ class StemConvFn(torch.autograd.Function):
     @once
     def backward(ctx, gy, _gstats):
         x, w = ctx.saved_tensors
-        gw = _conv_wgrad_raw(x, _c(gy), ctx.cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
-        return None, gw, None
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        B, T, H, W, _ = x.shape
+        # weight gradient on the matrix cores: per output position the 8x8 patch of the clip as 64 channels, then a
+        # 5-tap convolution along t (one 64x64 tile of 5 taps instead of 245 single-channel taps)
+        oh, ow = ctx.cfg.oh, ctx.cfg.ow
+        xp = torch.empty((B, T, oh * ow, 64), device=x.device, dtype=torch.float32)
+        check(_lib.lib().vca_stem_patches_f32(B, T, H, W, ptr(x), ptr(xp), stream()), 'stem_patches')
+        cfg = ConvCfg((64, 64, 5, 1), xp.shape, 1, (2, 0), 0)
+        g5 = _conv_wgrad_raw(xp, _c(gy).view(B, T, oh * ow, 64), cfg)                  # (co, kh*8+kw, kt, 1)
+        gw = g5.view(64, 8, 8, 5).permute(0, 3, 1, 2)[:, :, :7, :7].reshape(w.shape)
+        sink = _grad_sink(w)
+        if sink is not None:
+            sink.add_(gw)
+            return None, None, None
+        return None, gw.contiguous(), None
 
 
 def conv3d_stem(x, w, stride=2, pad=(2, 3, 3)):
