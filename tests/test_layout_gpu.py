@@ -180,3 +180,36 @@ def test_untiled_condition_head_equals_explicit_concat():
     for i, (a, b) in enumerate(zip(res[False], res[True])):
         err = float((a - b).abs().max())
         assert err <= 2e-4 * float(a.abs().max()) + 1e-6, (i, err, float(a.abs().max()))
+
+
+@gpu
+def test_subpixel_upsample_block_equals_upsampled_convolution():
+    """GenResBlk(upsample=True) in sub-pixel form (four tap-merged 3x3 convolutions of the source map) equals the
+    5x5 convolution of the nearest x2 upsampled map (generator.py:112-126): output, running statistics, input
+    gradient and every parameter gradient.  fp32 kernels."""
+    import copy
+    from vcagan_amd import ops
+    from vcagan_amd.models import generator as G
+    ops.set_precision('fp32')
+    torch.manual_seed(13)
+    blk = G.GenResBlk(32, 16, upsample=True).cuda().train()
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.add_(torch.randn_like(prm) * 0.05)
+    blk2 = copy.deepcopy(blk)
+    x0 = torch.randn(2, 6, 9, 32, device='cuda')
+    gy = torch.randn(2, 12, 18, 16, device='cuda')
+    res = []
+    for b, sub in ((blk, False), (blk2, True)):
+        G.SUBPIXEL_UPSAMPLE = sub
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = b(x)
+            y.backward(gy)
+        finally:
+            G.SUBPIXEL_UPSAMPLE = True
+        res.append([y.detach(), x.grad] + [p.grad for p in b.parameters()] + [t.float() for t in b.buffers()])
+    names = ['output', 'input gradient'] + [n for n, _ in blk.named_parameters()] + [n for n, _ in blk.named_buffers()]
+    for n, u, v in zip(names, res[0], res[1]):
+        err = float((u - v).abs().max())
+        assert err <= 2e-4 * float(u.abs().max()) + 2e-5, (n, err, float(u.abs().max()))

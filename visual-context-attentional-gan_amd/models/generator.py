@@ -14,6 +14,7 @@ from .. import ops
 from .resnet import BasicBlock
 
 _RSQRT2 = 1.0 / math.sqrt(2.0)
+SUBPIXEL_UPSAMPLE = True   # False: 5x5 convolution reading through the nearest x2 upsample (the reference's formulation)
 TILED_INPUT = True     # False: build the (B, 20, T, 640) decoder input explicitly (the reference's formulation)
 
 
@@ -75,8 +76,38 @@ class GenResBlk(nn.Module):
         self.norm2 = nn.BatchNorm2d(dim_out)
         if self.learned_sc:
             self.conv1x1 = nn.Conv2d(dim_in, dim_out, 1, 1, 0, bias=False)
+        if upsample:
+            # tap-merging matrices of the sub-pixel form: for output parity p, A[p] (3x5) sums the 5 kernel taps that
+            # read the same source pixel of the nearest x2 upsampled map
+            self.register_buffer('_tapmerge', torch.tensor(
+                [[[1, 1, 0, 0, 0], [0, 0, 1, 1, 0], [0, 0, 0, 0, 1]],
+                 [[1, 0, 0, 0, 0], [0, 1, 1, 0, 0], [0, 0, 0, 1, 1]]], dtype=torch.float32), persistent=False)
+
+    def _forward_subpixel(self, x):
+        """The up-sampling block (generator.py:112-126: nearest x2, then conv1 5x5 pad 2 / conv1x1) without reading
+        every source pixel four times: output pixels of parity (py, px) see only 3x3 distinct source pixels, so the
+        5x5 convolution of the upsampled map is four 3x3 pad-1 convolutions of the source map with tap-merged weights
+        (computed here as one convolution with 4*Cout channels, then interleaved), 9 taps per output instead of 25;
+        the 1x1 shortcut commutes with the upsample."""
+        assert self.learned_sc and tuple(self.conv1.kernel_size) == (5, 5) and tuple(self.conv1.padding) == (2, 2)
+        B, H, W, ci = x.shape
+        co = self.conv1.out_channels
+        A = self._tapmerge
+        w = self.conv1.weight
+        t = (w.view(co, ci, 1, 1, 5, 5) * A.view(1, 1, 2, 3, 5, 1)).sum(4)                 # (co, ci, py, a, kw)
+        t = (t.view(co, ci, 2, 3, 1, 1, 5) * A.view(1, 1, 1, 1, 2, 3, 5)).sum(6)           # (co, ci, py, a, px, b)
+        w3 = t.permute(2, 4, 0, 1, 3, 5).reshape(4 * co, ci, 3, 3)
+        a = ops.bn_act(x, self.norm1, ops.LEAKY)
+        y4 = ops.conv2d(a, w3, self.conv1.bias.repeat(4), 1, 1)                             # (B, H, W, (py, px, co))
+        r = y4.view(B, H, W, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, co)
+        r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
+        s = _conv(x, self.conv1x1)
+        s = s.view(B, H, 1, W, 1, co).expand(B, H, 2, W, 2, co).reshape(B, 2 * H, 2 * W, co)
+        return ops.add_scale(r, s, _RSQRT2)
 
     def forward(self, x):
+        if self.upsample and SUBPIXEL_UPSAMPLE:
+            return self._forward_subpixel(x)
         ups = 1 if self.upsample else 0
         r, st = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups, want_stats=True)   # nearest x2 read inside the conv
         r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY, stats=st), self.conv2)
