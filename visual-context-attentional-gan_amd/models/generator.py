@@ -55,10 +55,13 @@ class ResBlk(nn.Module):
             self.conv1x1 = nn.Conv2d(dim_in, dim_out, 1, 1, 0, bias=False)
 
     def forward(self, x):                                     # (B, H, W, C)
-        s = _conv(x, self.conv1x1) if self.learned_sc else x
+        # shortcut (generator.py:71-77: 1x1 convolution, then 2x2 average): both are linear and the convolution is
+        # pointwise, so they commute; pooling first runs the convolution on a quarter of the positions
+        s = ops.avgpool2(x) if self.downsample else x
+        s = _conv(s, self.conv1x1) if self.learned_sc else s
         r = _conv(ops.leaky(x), self.conv1)
         if self.downsample:
-            s, r = ops.avgpool2(s), ops.avgpool2(r)
+            r = ops.avgpool2(r)
         r = _conv(ops.leaky(r), self.conv2)
         return ops.add_scale(s, r, _RSQRT2)
 
