@@ -186,6 +186,16 @@ int vca_gru_cell_fwd_f32(int B, int H, const float* gi, const float* gh, const f
 int vca_gru_cell_bwd_f32(int B, int H, const float* dout, int dout_stride, const float* dh_a, const float* dh_b,
                          const float* save, const float* h_prev, float* d_gi, float* d_gh, float* dh_direct,
                          void* stream);
+/* The two directions of a bidirectional layer (visual_front.py:20, bidirectional=True) in one launch each: same
+ * arithmetic as vca_gru_cell_fwd_f32 / vca_gru_cell_bwd_f32 with every pointer given once per direction (h_prev,
+ * dh_a, dh_b may be NULL per direction). */
+int vca_gru_cell_fwd2_f32(int B, int H, int out_stride, const float* gi0, const float* gi1, const float* gh0,
+                          const float* gh1, const float* hp0, const float* hp1, float* hn0, float* hn1, float* out0,
+                          float* out1, float* save0, float* save1, void* stream);
+int vca_gru_cell_bwd2_f32(int B, int H, int dout_stride, const float* dout0, const float* dout1, const float* dha0,
+                          const float* dha1, const float* dhb0, const float* dhb1, const float* save0,
+                          const float* save1, const float* hp0, const float* hp1, float* dgi0, float* dgi1,
+                          float* dgh0, float* dgh1, float* dhd0, float* dhd1, void* stream);
 
 /* Latency-oriented GEMM for the recurrent products: y_i[M][N] = x_i[M][K] . W_i^T (+ bias_i) for nprob = 1 or 2
  * independent problems of the same shape in one launch (the two directions of a bidirectional layer).

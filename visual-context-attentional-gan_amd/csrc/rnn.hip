@@ -58,7 +58,83 @@ __global__ __launch_bounds__(THR) void gru_cell_bwd_kernel(int B, int H, const f
   dh_direct[i] = dh * z;
 }
 
+// Both directions of a bidirectional layer in one launch (blockIdx.y = direction): the recurrence is a chain of
+// small dependent launches, so each launch saved shortens the step.
+struct CellFwd2 {
+  const float* gi[2]; const float* gh[2]; const float* h_prev[2];
+  float* h_new[2]; float* out[2]; float* save[2];
+};
+
+__global__ __launch_bounds__(THR) void gru_cell_fwd2_kernel(int B, int H, int out_stride, CellFwd2 a) {
+  const int i = blockIdx.x * THR + threadIdx.x, d = blockIdx.y;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  const float* gib = a.gi[d] + (size_t)b * 3 * H;
+  const float* ghb = a.gh[d] + (size_t)b * 3 * H;
+  const float r = sigmoidf_(gib[j] + ghb[j]);
+  const float z = sigmoidf_(gib[H + j] + ghb[H + j]);
+  const float hn = ghb[2 * H + j];
+  const float n = tanhf(gib[2 * H + j] + r * hn);
+  const float hp = a.h_prev[d] ? a.h_prev[d][i] : 0.f;
+  const float h = (1.f - z) * n + z * hp;
+  a.h_new[d][i] = h;
+  a.out[d][(size_t)b * out_stride + j] = h;
+  float* sv = a.save[d] + (size_t)b * 4 * H;
+  sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = hn;
+}
+
+struct CellBwd2 {
+  const float* dout[2]; const float* dh_a[2]; const float* dh_b[2]; const float* save[2]; const float* h_prev[2];
+  float* d_gi[2]; float* d_gh[2]; float* dh_direct[2];
+};
+
+__global__ __launch_bounds__(THR) void gru_cell_bwd2_kernel(int B, int H, int dout_stride, CellBwd2 a) {
+  const int i = blockIdx.x * THR + threadIdx.x, d = blockIdx.y;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  float dh = a.dout[d][(size_t)b * dout_stride + j];
+  if (a.dh_a[d]) dh += a.dh_a[d][i];
+  if (a.dh_b[d]) dh += a.dh_b[d][i];
+  const float* sv = a.save[d] + (size_t)b * 4 * H;
+  const float r = sv[j], z = sv[H + j], n = sv[2 * H + j], hn = sv[3 * H + j];
+  const float hp = a.h_prev[d] ? a.h_prev[d][i] : 0.f;
+  const float dn = dh * (1.f - z) * (1.f - n * n);
+  const float dz = dh * (hp - n) * z * (1.f - z);
+  const float dr = dn * hn * r * (1.f - r);
+  float* gi = a.d_gi[d] + (size_t)b * 3 * H;
+  float* gh = a.d_gh[d] + (size_t)b * 3 * H;
+  gi[j] = dr; gi[H + j] = dz; gi[2 * H + j] = dn;
+  gh[j] = dr; gh[H + j] = dz; gh[2 * H + j] = dn * r;
+  a.dh_direct[d][i] = dh * z;
+}
+
 }  // namespace
+
+extern "C" int vca_gru_cell_fwd2_f32(int B, int H, int out_stride, const float* gi0, const float* gi1,
+                                     const float* gh0, const float* gh1, const float* hp0, const float* hp1,
+                                     float* hn0, float* hn1, float* out0, float* out1, float* save0, float* save1,
+                                     void* stream) {
+  VCA_CHECK_ARG(B > 0 && H > 0 && gi0 && gi1 && gh0 && gh1 && hn0 && hn1 && out0 && out1 && save0 && save1 &&
+                out_stride >= H);
+  CellFwd2 a{{gi0, gi1}, {gh0, gh1}, {hp0, hp1}, {hn0, hn1}, {out0, out1}, {save0, save1}};
+  hipLaunchKernelGGL(gru_cell_fwd2_kernel, dim3((B * H + THR - 1) / THR, 2), dim3(THR), 0, (hipStream_t)stream, B, H,
+                     out_stride, a);
+  return vca_launch_status();
+}
+
+extern "C" int vca_gru_cell_bwd2_f32(int B, int H, int dout_stride, const float* dout0, const float* dout1,
+                                     const float* dha0, const float* dha1, const float* dhb0, const float* dhb1,
+                                     const float* save0, const float* save1, const float* hp0, const float* hp1,
+                                     float* dgi0, float* dgi1, float* dgh0, float* dgh1, float* dhd0, float* dhd1,
+                                     void* stream) {
+  VCA_CHECK_ARG(B > 0 && H > 0 && dout0 && dout1 && save0 && save1 && dgi0 && dgi1 && dgh0 && dgh1 && dhd0 && dhd1 &&
+                dout_stride >= H);
+  CellBwd2 a{{dout0, dout1}, {dha0, dha1}, {dhb0, dhb1}, {save0, save1}, {hp0, hp1},
+             {dgi0, dgi1}, {dgh0, dgh1}, {dhd0, dhd1}};
+  hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3((B * H + THR - 1) / THR, 2), dim3(THR), 0, (hipStream_t)stream, B, H,
+                     dout_stride, a);
+  return vca_launch_status();
+}
 
 extern "C" int vca_gru_cell_fwd_f32(int B, int H, const float* gi, const float* gh, const float* h_prev, float* h_new,
                                     float* out, int out_stride, float* save, void* stream) {

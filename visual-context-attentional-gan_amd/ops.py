@@ -1086,11 +1086,11 @@ class GruLayerFn(torch.autograd.Function):
             ts = (s, T - 1 - s)
             hp = [h0 if s == 0 else hbuf[0][s - 1], h0 if s == 0 else hbuf[1][T - s]]
             gh = _rec_gemm(hp, w_hh, b_hh, 0)
-            for d in range(2):
-                t = ts[d]
-                check(L.vca_gru_cell_fwd_f32(B, H, ptr(gi[d][t]), ptr(gh[d]), ptr(hp[d]), ptr(hbuf[d][t]),
-                                             out[t].data_ptr() + 4 * d * H, 2 * H, ptr(save[d][t]), stream()),
-                      'gru_cell_fwd')
+            t0, t1 = ts
+            check(L.vca_gru_cell_fwd2_f32(B, H, 2 * H, ptr(gi[0][t0]), ptr(gi[1][t1]), ptr(gh[0]), ptr(gh[1]),
+                                          ptr(hp[0]), ptr(hp[1]), ptr(hbuf[0][t0]), ptr(hbuf[1][t1]),
+                                          out[t0].data_ptr(), out[t1].data_ptr() + 4 * H, ptr(save[0][t0]),
+                                          ptr(save[1][t1]), stream()), 'gru_cell_fwd2')
         ctx.save_for_backward(x, *wts, hbuf[0], save[0], hbuf[1], save[1])
         return out
 
@@ -1116,13 +1116,14 @@ class GruLayerFn(torch.autograd.Function):
         dh_gemm, dh_dir = [None, None], [None, None]
         for s in range(T):
             ts = (T - 1 - s, s)
-            for d in range(2):
-                t = ts[d]
-                nd = torch.empty((B, H), device=dev, dtype=torch.float32)
-                check(L.vca_gru_cell_bwd_f32(B, H, dout[t].data_ptr() + 4 * d * H, 2 * H, ptr(dh_gemm[d]),
-                                             ptr(dh_dir[d]), ptr(save[d][t]), ptr(hprev[d][t]), ptr(d_gi[d][t]),
-                                             ptr(d_gh[d][t]), ptr(nd), stream()), 'gru_cell_bwd')
-                dh_dir[d] = nd
+            t0, t1 = ts
+            nd = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
+            check(L.vca_gru_cell_bwd2_f32(B, H, 2 * H, dout[t0].data_ptr(), dout[t1].data_ptr() + 4 * H,
+                                          ptr(dh_gemm[0]), ptr(dh_gemm[1]), ptr(dh_dir[0]), ptr(dh_dir[1]),
+                                          ptr(save[0][t0]), ptr(save[1][t1]), ptr(hprev[0][t0]), ptr(hprev[1][t1]),
+                                          ptr(d_gi[0][t0]), ptr(d_gi[1][t1]), ptr(d_gh[0][t0]), ptr(d_gh[1][t1]),
+                                          ptr(nd[0]), ptr(nd[1]), stream()), 'gru_cell_bwd2')
+            dh_dir = nd
             if s + 1 < T:
                 dh_gemm = _rec_gemm([d_gh[0][ts[0]], d_gh[1][ts[1]]], w_hh, [None, None], 1)
         dx = None
