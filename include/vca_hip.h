@@ -148,6 +148,12 @@ int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const 
                            const float* alpha, const float* res, const float* mean, const float* invstd, int act,
                            float slope, float oscale, int train, float* sums, float* gx, float* gres, void* stream);
 
+/* BatchNorm3d -> PReLU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the front-end (visual_front.py:12-14) without the
+ * activated full-resolution map: writes the pooled map [N][OH][OW][C] and the argmax taps (0..8) straight from
+ * x [N][H][W][C] and the batch-norm coefficients.  Backward: vca_maxpool3s2_bwd_f32, then vca_affine_act_bwd_f32. */
+int vca_affine_act_pool3_fwd_f32(int N, int H, int W, int C, const float* x, const float* scale, const float* shift,
+                                 const float* alpha, int act, float slope, float* y, unsigned char* idx, void* stream);
+
 /* 2x2 pooling family on [N][H][W][C] (F.avg_pool2d(x,2) generator.py:74,83; nearest x2 upsample :112,121).
  * (Hs,Ws) is the small map, (Hl,Wl) the large one, Hs = Hl/2, Ws = Wl/2.
  * mode 0: average large->small; 1: its adjoint small->large; 2: block sum large->small; 3: nearest upsample. */

@@ -246,3 +246,32 @@ def test_sync_loss_heads(B, T, C, temp):
     a = a0.cuda().requires_grad_(True)
     ops.sync_loss(v0.cuda(), a, temp, True).sum().backward()
     assert a.grad is not None and torch.isfinite(a.grad).all()
+
+
+@gpu
+@pytest.mark.parametrize('train', [True, False])
+def test_bn_act_maxpool3_fused_equals_separate_ops(train):
+    """BatchNorm -> PReLU -> MaxPool(3x3, s2, p1) as one kernel pair (visual_front.py:12-14) vs the separate ops:
+    output, running statistics, input gradient, gamma/beta/alpha gradients."""
+    import copy
+    from vcagan_amd import ops
+    torch.manual_seed(21)
+    bn = torch.nn.BatchNorm2d(16).cuda().train(train)
+    pr = torch.nn.PReLU(16).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+        pr.weight.uniform_(0.1, 0.4)
+    bn2, pr2 = copy.deepcopy(bn), copy.deepcopy(pr)
+    x0 = torch.randn(3, 10, 14, 16, device='cuda')
+    gy = torch.randn(3, 5, 7, 16, device='cuda')
+    xa = x0.clone().requires_grad_(True)
+    ya = ops.maxpool3x3s2(ops.bn_act(xa, bn, pr))
+    ya.backward(gy)
+    xb = x0.clone().requires_grad_(True)
+    yb = ops.bn_act_maxpool3(xb, bn2, pr2)
+    yb.backward(gy)
+    assert torch.allclose(ya, yb, atol=1e-6)
+    assert torch.allclose(xa.grad, xb.grad, atol=2e-6, rtol=1e-5)
+    for u, v in ((bn.weight, bn2.weight), (bn.bias, bn2.bias), (pr.weight, pr2.weight)):
+        assert torch.allclose(u.grad, v.grad, atol=1e-4, rtol=1e-5), float((u.grad - v.grad).abs().max())
+    assert torch.allclose(bn.running_mean, bn2.running_mean) and torch.allclose(bn.running_var, bn2.running_var)

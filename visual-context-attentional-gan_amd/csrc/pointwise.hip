@@ -360,6 +360,46 @@ __global__ __launch_bounds__(THR) void maxpool3_fwd_kernel(int N, int H, int W, 
   }
 }
 
+// y = maxpool3x3s2(act(x*scale + shift)) in one pass over x (visual_front.py:12-14: BatchNorm3d -> PReLU ->
+// MaxPool3d((1,3,3),(1,2,2),(0,1,1))): the activated full-resolution map is never written.
+__global__ __launch_bounds__(THR) void affine_act_pool3_kernel(int N, int H, int W, int OH, int OW, int C, int act,
+                                                               float slope, const float* __restrict__ x,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ alpha,
+                                                               float* __restrict__ y, unsigned char* __restrict__ idx) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)N * OH * OW * C4;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int ow = r % OW; r /= OW;
+    const int oh = r % OH;
+    const int n = r / OH;
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    float sl[4] = {slope, slope, slope, slope};
+    if (act == VCA_ACT_PRELU) {
+      const float4 al = ld4(alpha + c);
+      sl[0] = al.x; sl[1] = al.y; sl[2] = al.z; sl[3] = al.w;
+    }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh * 2 - 1 + t / 3, iw = ow * 2 - 1 + t % 3;
+      if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+      const float4 v = ld4(x + (((size_t)n * H + ih) * W + iw) * C + c);
+      const float vv[4] = {act_fwd(v.x * sc.x + sh.x, act, sl[0]), act_fwd(v.y * sc.y + sh.y, act, sl[1]),
+                           act_fwd(v.z * sc.z + sh.z, act, sl[2]), act_fwd(v.w * sc.w + sh.w, act, sl[3])};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (vv[j] > best[j] || vv[j] != vv[j]) { best[j] = vv[j]; bi[j] = t; }
+    }
+    st4(y + i * 4, make_float4(best[0], best[1], best[2], best[3]));
+    *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+  }
+}
+
 __global__ __launch_bounds__(THR) void maxpool3_bwd_kernel(int N, int H, int W, int OH, int OW, int C,
                                                            const float* __restrict__ gy,
                                                            const unsigned char* __restrict__ idx,
@@ -499,5 +539,16 @@ extern "C" int vca_maxpool3s2_bwd_f32(int N, int H, int W, int C, const float* g
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(THR), 0,
                      (hipStream_t)stream, N, H, W, OH, OW, C, gy, idx, gx);
+  return vca_launch_status();
+}
+
+extern "C" int vca_affine_act_pool3_fwd_f32(int N, int H, int W, int C, const float* x, const float* scale,
+                                            const float* shift, const float* alpha, int act, float slope, float* y,
+                                            unsigned char* idx, void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && x && scale && shift && y && idx);
+  VCA_CHECK_ARG(act >= 0 && act <= 4 && (act != VCA_ACT_PRELU || alpha));
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(affine_act_pool3_kernel, dim3(grid_for((size_t)N * OH * OW * (C / 4))), dim3(THR), 0,
+                     (hipStream_t)stream, N, H, W, OH, OW, C, act, slope, x, scale, shift, alpha, y, idx);
   return vca_launch_status();
 }

@@ -23,8 +23,9 @@ class Visual_front(nn.Module):
         """x: (B, 1, T, H, W) video.  Returns phonemes (B, T, 512) and sentence features (B, 512, T)."""
         B, _, T, H, W = x.shape
         f, stats = ops.conv3d_stem(x.reshape(B, T, H, W, 1), self.frontend[0].weight)   # (B,T,H/2,W/2,64)
-        f = ops.bn_act(f, self.frontend[1], self.frontend[2], stats=stats)
-        f = ops.maxpool3x3s2(f.view(B * T, f.shape[2], f.shape[3], 64))              # frames flattened for free
+        # BatchNorm3d -> PReLU -> MaxPool3d in one pass; frames flattened for free (channels-last)
+        f = ops.bn_act_maxpool3(f.view(B * T, f.shape[2], f.shape[3], 64), self.frontend[1], self.frontend[2],
+                                stats=stats)
         f = self.resnet(f)                                                           # (B*T, 512)
         f = ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
         sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)

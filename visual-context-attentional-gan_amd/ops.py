@@ -806,6 +806,50 @@ class MaxPool3Fn(torch.autograd.Function):
         return gx
 
 
+class BnActPool3Fn(torch.autograd.Function):
+    """maxpool3x3s2(act(batch_norm(x))) in one forward pass (visual_front.py:12-14); the activated full-resolution
+    map is neither written nor kept.  Backward: the pooled gradient is scattered through the saved argmax taps, then
+    the ordinary batch-norm backward runs on x.  (Gathering the pooled gradient inside the two batch-norm backward
+    passes instead was measured slower: the gather costs more than the pass it saves.)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, coef, act, slope, train):
+        x = _c(x)
+        n, h, w, c = x.shape
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        check(_lib.lib().vca_affine_act_pool3_fwd_f32(n, h, w, c, ptr(x), ptr(coef[2]), ptr(coef[3]), ptr(alpha), act,
+                                                      slope, ptr(y), idx.data_ptr(), stream()), 'affine_act_pool3')
+        ctx.save_for_backward(x, alpha, coef, idx)
+        ctx.cfg = (act, slope, train)
+        return y
+
+    @staticmethod
+    @once
+    def backward(ctx, gy):
+        x, alpha, coef, idx = ctx.saved_tensors
+        act, slope, train = ctx.cfg
+        n, h, w, c = x.shape
+        L = _lib.lib()
+        g = torch.empty_like(x)
+        check(L.vca_maxpool3s2_bwd_f32(n, h, w, c, ptr(_c(gy)), idx.data_ptr(), ptr(g), stream()), 'maxpool_bwd')
+        sums = torch.zeros((16, 3, c), device=x.device, dtype=torch.float32)   # VCA_BN_SLOTS
+        gx = torch.empty_like(x)
+        check(L.vca_affine_act_bwd_f32(n * h * w, c, ptr(g), ptr(x), ptr(coef[2]), ptr(coef[3]), ptr(alpha), None,
+                                       ptr(coef[0]), ptr(coef[1]), act, slope, 1.0, 1 if train else 0, ptr(sums),
+                                       ptr(gx), None, stream()), 'affine_act_bwd')
+        galpha = sums[0, 2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
+        return (gx if ctx.needs_input_grad[0] else None), sums[0, 1], sums[0, 0], galpha, None, None, None, None
+
+
+def bn_act_maxpool3(x, bn, act=None, stats=None):
+    """maxpool3x3s2(act(batch_norm(x))) on a channels-last map (N,H,W,C) as one kernel."""
+    code, slope, alpha = _act_code(act)
+    coef, train = _bn_coef(x, bn, stats)
+    return BnActPool3Fn.apply(x, bn.weight, bn.bias, alpha, coef, code, slope, train)
+
+
 def maxpool3x3s2(x):
     """MaxPool (3x3, stride 2, pad 1) on a channels-last map (visual_front.py:14)."""
     return MaxPool3Fn.apply(x)
