@@ -404,39 +404,65 @@ __global__ __launch_bounds__(THR) void maxpool3_bwd_kernel(int N, int H, int W, 
                                                            const float* __restrict__ gy,
                                                            const unsigned char* __restrict__ idx,
                                                            float* __restrict__ gx) {
+  // One thread per 2x2 block of input pixels (rows 2a, 2a+1; columns 2b, 2b+1) and 4 channels: with stride 2 the
+  // block is touched by exactly the windows (a | a+1, b | b+1), so each window's gradient and argmax are loaded
+  // once for the four pixels (window (oh, ow) covers rows 2oh-1..2oh+1, tap = 3*(ih-2oh+1) + (iw-2ow+1)).
   const int C4 = C >> 2;
-  const size_t total = (size_t)N * H * W * C4;
+  const int HB = (H + 1) >> 1, WB = (W + 1) >> 1;
+  const size_t total = (size_t)N * HB * WB * C4;
   for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
     const int c = (int)(i % C4) * 4;
     size_t r = i / C4;
-    const int iw = r % W; r /= W;
-    const int ih = r % H;
-    const int n = r / H;
-    float o[4] = {0, 0, 0, 0};
-    // output windows covering (ih, iw): oh in {(ih+1)/2 - ?}: oh*2-1+dy = ih, dy in 0..2
+    const int b = r % WB; r /= WB;
+    const int a = r % HB;
+    const int n = r / HB;
+    float o[2][2][4];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int t = ih + 1 - dy;
-      if (t < 0 || (t & 1)) continue;
-      const int oh = t >> 1;
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[p][q][e] = 0.f;
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy) {
+      const int oh = a + wy;
       if (oh >= OH) continue;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int u = iw + 1 - dx;
-        if (u < 0 || (u & 1)) continue;
-        const int ow = u >> 1;
+      for (int wx = 0; wx < 2; ++wx) {
+        const int ow = b + wx;
         if (ow >= OW) continue;
         const size_t oi = (((size_t)n * OH + oh) * OW + ow) * C + c;
-        const uchar4 k = *reinterpret_cast<const uchar4*>(idx + oi);
-        const float4 g = ld4(gy + oi);
-        const int tap = dy * 3 + dx;
-        if (k.x == tap) o[0] += g.x;
-        if (k.y == tap) o[1] += g.y;
-        if (k.z == tap) o[2] += g.z;
-        if (k.w == tap) o[3] += g.w;
+        const uchar4 k4 = *reinterpret_cast<const uchar4*>(idx + oi);
+        const float4 g4 = ld4(gy + oi);
+        const int k[4] = {k4.x, k4.y, k4.z, k4.w};
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int dy = p + 1 - 2 * wy;          // row 2a+p inside window a+wy
+          if (dy < 0 || dy > 2) continue;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int dx = q + 1 - 2 * wx;
+            if (dx < 0 || dx > 2) continue;
+            const int tap = dy * 3 + dx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k[e] == tap) o[p][q][e] += g[e];
+          }
+        }
       }
     }
-    st4(gx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int ih = 2 * a + p;
+      if (ih >= H) continue;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int iw = 2 * b + q;
+        if (iw >= W) continue;
+        st4(gx + (((size_t)n * H + ih) * W + iw) * C + c, make_float4(o[p][q][0], o[p][q][1], o[p][q][2], o[p][q][3]));
+      }
+    }
   }
 }
 
@@ -537,7 +563,7 @@ extern "C" int vca_maxpool3s2_bwd_f32(int N, int H, int W, int C, const float* g
                                       float* gx, void* stream) {
   VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && gy && gx && idx);
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(THR), 0,
+  hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_for((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4))), dim3(THR), 0,
                      (hipStream_t)stream, N, H, W, OH, OW, C, gy, idx, gx);
   return vca_launch_status();
 }
