@@ -189,35 +189,54 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
   const int row = m0 + lr;
   const bool rv = row < a.M;
   const bool vec = (a.K % 4) == 0;
-  for (int ks = ks_beg; ks < ks_end; ++ks) {
-    const int k0 = ks * 16 + lh * 8;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (rv) {
-      const float* src = x + (size_t)row * a.K + k0;
-      if (vec && k0 + 8 <= a.K) {
-        const float4 p = *reinterpret_cast<const float4*>(src), q = *reinterpret_cast<const float4*>(src + 4);
-        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-      } else {
+  // The reduction is walked in chunks of CH k-steps; all global loads of a chunk (A rows and weight fragments) are
+  // issued before the first MFMA, so a wave pays the memory latency once per chunk instead of once per k-step.
+  constexpr int CH = 8;
+  for (int base = ks_beg; base < ks_end; base += CH) {
+    float4 ap[CH], aq[CH];
+    bf16x8 bh[CH], bl[CH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (k0 + j < a.K) v[j] = src[j];
+    for (int j = 0; j < CH; ++j) {
+      const int ks = base + j;
+      const int k0 = ks * 16 + lh * 8;
+      ap[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      aq[j] = ap[j];
+      const bool kv = ks < ks_end;
+      if (rv && kv) {
+        const float* src = x + (size_t)row * a.K + k0;
+        if (vec && k0 + 8 <= a.K) {
+          ap[j] = *reinterpret_cast<const float4*>(src);
+          aq[j] = *reinterpret_cast<const float4*>(src + 4);
+        } else {
+          float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + e < a.K) v[e] = src[e];
+          ap[j] = make_float4(v[0], v[1], v[2], v[3]);
+          aq[j] = make_float4(v[4], v[5], v[6], v[7]);
+        }
       }
+      // weight row n0+lr of slice ks>>1: 128 B = [hi 32 | lo 32]; this lane's 8 values start at (ks&1)*16 + lh*8
+      const int ksc = kv ? ks : ks_beg;        // past the end: any valid address, the A operand is zero
+      const unsigned char* wp = w + ((size_t)(ksc >> 1) * a.npad + n0 + lr) * 128 + ((ksc & 1) * 16 + lh * 8) * 2;
+      bh[j] = *reinterpret_cast<const bf16x8*>(wp);
+      if (a.nsplit == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wp + 64);
     }
-    bf16x8 ah, al;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ah[j] = (__bf16)v[j];
-      al[j] = (__bf16)(v[j] - (float)ah[j]);
+    for (int j = 0; j < CH; ++j) {
+      const float v[8] = {ap[j].x, ap[j].y, ap[j].z, ap[j].w, aq[j].x, aq[j].y, aq[j].z, aq[j].w};
+      bf16x8 ah, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ah[e] = (__bf16)v[e];
+        al[e] = (__bf16)(v[e] - (float)ah[e]);
+      }
+      if (a.nsplit == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc, 0, 0, 0);
     }
-    // weight row n0+lr of slice ks>>1: 128 B = [hi 32 | lo 32]; this lane's 8 values start at (ks&1)*16 + lh*8
-    const unsigned char* wp = w + ((size_t)(ks >> 1) * a.npad + n0 + lr) * 128 + ((ks & 1) * 16 + lh * 8) * 2;
-    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
-    if (a.nsplit == 3) {
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + 64);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
