@@ -932,7 +932,7 @@ int launch_halo(HArgs a, int gx, int gy, size_t lds, hipStream_t s) {
   const long long blocks = (long long)gx * gy;
   if (blocks < 224 && a.nchunk >= 4 && !a.res && !a.stats && a.d.out_scale == 1.0f) {
     int ks = (int)((448 + blocks - 1) / blocks);
-    if (ks > a.nchunk / 2) ks = a.nchunk / 2;
+    if (ks > a.nchunk) ks = a.nchunk;       // down to one 32-channel slice per workgroup
     if (ks > 1) {
       a.ksplit = ks;
       vca_zero_async(a.y, (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout, s);
