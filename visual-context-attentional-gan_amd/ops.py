@@ -23,8 +23,16 @@ once = torch.autograd.function.once_differentiable
 # --------------------------------------------------------------------------- #
 # weight packing
 # --------------------------------------------------------------------------- #
-_param_epoch = [0]   # bumped whenever parameters are rewritten behind autograd's back (fused Adam, re-homing)
+_param_epoch = [0]   # bumped whenever parameters are rewritten behind autograd's back (re-homing, checkpoint load)
 _pack_cache = {}     # id(parameter) -> (weakref, {mode: (version, packed tensor)})
+
+
+def _wkey(w):
+    """Validity key of a packed copy of w: autograd's version counter, the global epoch, and the epoch of the flat
+    buffer the parameter lives in (bumped by the fused Adam step that rewrites exactly that buffer, so one
+    network's step does not invalidate the packed weights of the others)."""
+    ep = getattr(w, '_vca_epoch', None)
+    return (w._version, _param_epoch[0], ep[0] if ep is not None else 0)
 
 
 def _wdims(w):
@@ -58,17 +66,28 @@ def _pack(w, mode):
     cacheable = isinstance(w, torch.nn.Parameter)
     if cacheable:
         ent = _pack_cache.get(id(w))
-        if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == (w._version, _param_epoch[0]):
+        if ent is not None and ent[0]() is w and ent[1].get(mode, (None,))[0] == _wkey(w):
             return ent[1][mode][1]
     wd = w.detach().contiguous()
+    # A stale packed copy of the same parameter is overwritten in place: its address stays fixed, which captured
+    # graphs rely on (a convolution replayed early in a step reads what a pack replayed late in the previous
+    # step wrote).
+    old = None
+    if cacheable:
+        ent = _pack_cache.get(id(w))
+        if ent is not None and ent[0]() is w and mode in ent[1]:
+            old = ent[1][mode][1]
     if mode >= 10:
         nbytes = _lib.lib().vca_pack_weight_bf16_bytes(mode - 10, cout, cin, taps)
-        out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        out = old if (old is not None and old.numel() == nbytes and old.device == w.device) else \
+            torch.empty(nbytes, device=w.device, dtype=torch.uint8)
         check(_lib.lib().vca_pack_weight_bf16(mode - 10, cout, cin, taps, ptr(wd), out.data_ptr(), stream()),
               'pack_weight_bf16')
     else:
         row = ((cout + 3) // 4 * 4) if mode == 0 else ((cin + 3) // 4 * 4)
-        out = torch.empty((taps, cin if mode == 0 else cout, row), device=w.device, dtype=torch.float32)
+        shape = (taps, cin if mode == 0 else cout, row)
+        out = old if (old is not None and tuple(old.shape) == shape and old.device == w.device) else \
+            torch.empty(shape, device=w.device, dtype=torch.float32)
         check(_lib.lib().vca_pack_weight_f32(mode, cout, cin, taps, ptr(wd), ptr(out), 0.0, stream()), 'pack_weight')
     if cacheable:
         key = id(w)
@@ -76,7 +95,7 @@ def _pack(w, mode):
         if ent is None or ent[0]() is not w:
             ent = (weakref.ref(w, lambda _r, key=key: _pack_cache.pop(key, None)), {})
             _pack_cache[key] = ent
-        ent[1][mode] = ((w._version, _param_epoch[0]), out)
+        ent[1][mode] = (_wkey(w), out)
     return out
 
 
@@ -412,10 +431,11 @@ class StemConvFn(torch.autograd.Function):
         cacheable = isinstance(w, torch.nn.Parameter)
         if cacheable:
             ent = _pack_cache.get(id(w))
-            if ent is not None and ent[0]() is w and ent[1].get(key, (None,))[0] == (w._version, _param_epoch[0]):
+            if ent is not None and ent[0]() is w and ent[1].get(key, (None,))[0] == _wkey(w):
                 wp = ent[1][key][1]
         if wp is None:
-            wp = torch.empty(2 * 64 * 296 * 2, device=x.device, dtype=torch.uint8)
+            old = ent[1][key][1] if (cacheable and ent is not None and ent[0]() is w and key in ent[1]) else None
+            wp = old if old is not None else torch.empty(2 * 64 * 296 * 2, device=x.device, dtype=torch.uint8)
             check(L.vca_stem_pack_weight(ptr(_c(w.detach())), wp.data_ptr(), stream()), 'stem_pack')
             if cacheable:
                 k2 = id(w)
@@ -423,7 +443,7 @@ class StemConvFn(torch.autograd.Function):
                 if ent is None or ent[0]() is not w:
                     ent = (weakref.ref(w, lambda _r, k2=k2: _pack_cache.pop(k2, None)), {})
                     _pack_cache[k2] = ent
-                ent[1][key] = ((w._version, _param_epoch[0]), wp)
+                ent[1][key] = (_wkey(w), wp)
         y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
         stats = torch.zeros((2, 64), device=x.device, dtype=torch.float32)
         check(L.vca_stem_fwd_bf16(_nsplit(), B, T, H, W, ptr(x), wp.data_ptr(), ptr(y), ptr(stats), stream()),
@@ -1302,6 +1322,9 @@ def sync_loss(v_feat, a_feat, temp, gen):
 # --------------------------------------------------------------------------- #
 # flat parameter storage + fused Adam
 # --------------------------------------------------------------------------- #
+_flat_epoch = {}     # data_ptr of a flat parameter buffer -> its epoch cell (shared with its parameters)
+
+
 def flatten_module(module):
     """Re-home every parameter of `module` (already on its device) into one flat fp32 buffer and give it a flat,
     persistent gradient buffer: p.data and p.grad become views.  Returns (flat_params, flat_grads)."""
@@ -1312,12 +1335,15 @@ def flatten_module(module):
     flat = torch.zeros(total, device=dev, dtype=torch.float32)
     gflat = torch.zeros(total, device=dev, dtype=torch.float32)
     off = 0
+    epoch = [0]
     for p, sz in zip(ps, sizes):
         n = p.numel()
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view(p.shape)
         p.grad = gflat[off:off + n].view(p.shape)
+        p._vca_epoch = epoch
         off += sz
+    _flat_epoch[flat.data_ptr()] = epoch
     _param_epoch[0] += 1
     return flat, gflat
 
@@ -1347,4 +1373,8 @@ class FusedAdam:
             check(_lib.lib().vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
                                           self.t_dev.data_ptr(), stream()), 'adam')
-        _param_epoch[0] += 1
+            ep = _flat_epoch.get(f.data_ptr())
+            if ep is not None:
+                ep[0] += 1
+            else:
+                _param_epoch[0] += 1
