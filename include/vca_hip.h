@@ -95,6 +95,18 @@ int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, cons
                         const float* in_shift, const float* in_alpha, float* dwpack, void* stream);
 long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps);
 int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream);
+/* vca_pack_weight_bf16 for many weights in one launch (all packed copies of one network after its optimizer step;
+ * the reference has no counterpart: torch re-reads nn.Parameter storage directly).  table: ndesc records in DEVICE
+ * memory, sorted by tile_begin = running sum of ceil(K/32) * (roundup(N,32)/8) over the preceding records (N, K as
+ * in vca_pack_weight_bf16); total_tiles = that sum over all records; every record needs taps <= 32;
+ * max_taps = the largest taps in the table. */
+typedef struct vca_pack_desc {
+  const float* src;   /* [Cout][Cin][taps] */
+  void* dst;          /* vca_pack_weight_bf16_bytes(mode, Cout, Cin, taps) bytes */
+  int mode, Cout, Cin, taps;
+  int tile_begin, reserved;
+} vca_pack_desc;
+int vca_pack_weight_bf16_batch(const vca_pack_desc* table, int ndesc, int total_tiles, int max_taps, void* stream);
 
 /* Conv3d stem of the visual front-end (nn.Conv3d(1, 64, (5,7,7), (1,2,2), (2,3,3), bias=False),
  * visual_front.py:11) in split-bf16: x is the single-channel video [B][T][H][W], y the channels-last feature map

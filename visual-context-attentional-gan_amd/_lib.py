@@ -51,6 +51,7 @@ _SIGS = {
     'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 7, _I),
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
+    'vca_pack_weight_bf16_batch': ([_P, _I, _I, _I, _P], _I),
     'vca_stem_pack_weight': ([_P, _P, _P], _I),
     'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     'vca_stem_patches_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),

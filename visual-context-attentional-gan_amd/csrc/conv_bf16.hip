@@ -821,14 +821,12 @@ __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, i
 // Same packing for filters of at most 32 taps with coalesced traffic on both sides: a workgroup stages the
 // 32 k x 8 n x taps source values of one (channel slice, 8 output rows) group in LDS (the source is contiguous
 // over (k, tap) for a fixed n in mode 0 and over (n, tap) for a fixed k in mode 1) and writes whole 128-byte rows.
-__global__ __launch_bounds__(256) void pack_weight_bf16_tiled_kernel(int mode, int Cin, int taps, int N, int K,
-                                                                     int npad, int nchunk,
-                                                                     const float* __restrict__ src,
-                                                                     __bf16* __restrict__ dst) {
-  extern __shared__ float tl[];   // [8 n][32 k][taps]
-  const int chunk = blockIdx.x, n0 = blockIdx.y * 8, k0 = chunk * 32;
+__device__ __forceinline__ void pack_tile_bf16(int mode, int Cin, int taps, int N, int K, int npad, int nchunk,
+                                               const float* __restrict__ src, __bf16* __restrict__ dst, int chunk,
+                                               int n0, float* tl /* [8 n][32 k][taps] */) {
+  const int k0 = chunk * 32;
   const int tid = threadIdx.x;
-  const int per = 32 * taps, total = 8 * per;
+  const int per = 32 * taps;
   if (mode == 0) {
     const int rmax = min(K - k0, 32) * taps;          // entries of this slice that exist in the source
     for (int r = tid; r < per; r += 256) {
@@ -868,6 +866,36 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_tiled_kernel(int mode, i
       *reinterpret_cast<uint4*>(row + 64 + jq * 16) = l;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_bf16_tiled_kernel(int mode, int Cin, int taps, int N, int K,
+                                                                     int npad, int nchunk,
+                                                                     const float* __restrict__ src,
+                                                                     __bf16* __restrict__ dst) {
+  extern __shared__ float tl[];   // [8 n][32 k][taps]
+  pack_tile_bf16(mode, Cin, taps, N, K, npad, nchunk, src, dst, blockIdx.x, blockIdx.y * 8, tl);
+}
+
+// Every packed copy of a network's weights in one launch (after its optimizer step): the descriptors list the
+// (parameter, role) pairs with the first tile of each in a running count; a workgroup finds its descriptor by
+// bisection and packs one (channel slice, 8 rows) tile exactly as the single-weight kernel does.
+__global__ __launch_bounds__(256) void pack_weight_bf16_batch_kernel(const vca_pack_desc* __restrict__ table,
+                                                                     int ndesc) {
+  extern __shared__ float tl[];
+  const int tile = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile_begin <= tile) lo = mid;
+    else hi = mid - 1;
+  }
+  const vca_pack_desc d = table[lo];
+  const int local = tile - d.tile_begin;
+  const int K = d.mode == 0 ? d.Cin : d.Cout, N = d.mode == 0 ? d.Cout : d.Cin;
+  const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
+  if (local >= nchunk * (npad / 8)) return;
+  pack_tile_bf16(d.mode, d.Cin, d.taps, N, K, npad, nchunk, d.src, reinterpret_cast<__bf16*>(d.dst), local % nchunk,
+                 (local / nchunk) * 8, tl);
 }
 
 struct TileChoice {
@@ -1053,6 +1081,14 @@ extern "C" int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const
   const size_t total = (size_t)taps * nchunk * npad * 32;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      mode, Cout, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));
+  return vca_launch_status();
+}
+
+extern "C" int vca_pack_weight_bf16_batch(const vca_pack_desc* table, int ndesc, int total_tiles, int max_taps,
+                                          void* stream) {
+  VCA_CHECK_ARG(table && ndesc > 0 && total_tiles > 0 && max_taps > 0 && max_taps <= 32);
+  hipLaunchKernelGGL(pack_weight_bf16_batch_kernel, dim3(total_tiles), dim3(256),
+                     (size_t)8 * 32 * max_taps * sizeof(float), (hipStream_t)stream, table, ndesc);
   return vca_launch_status();
 }
 

@@ -1323,6 +1323,61 @@ def sync_loss(v_feat, a_feat, temp, gen):
 # flat parameter storage + fused Adam
 # --------------------------------------------------------------------------- #
 _flat_epoch = {}     # data_ptr of a flat parameter buffer -> its epoch cell (shared with its parameters)
+_flat_params = {}    # data_ptr of a flat parameter buffer -> its parameters
+
+
+class _RepackPlan:
+    """All split-bf16 packed copies of one flat buffer's weights, refreshed by a single launch after the optimizer
+    step that rewrote the buffer (instead of one small launch per weight and role at first use).  The descriptor
+    table is rebuilt when the set of packed copies changes; never while a graph is being captured (the per-use path
+    covers that step)."""
+
+    def __init__(self, params):
+        self.params = params
+        self.sig = None
+        self.table = None
+        self.meta = (0, 0, 0)
+
+    def _entries(self):
+        out = []
+        for p in self.params:
+            ent = _pack_cache.get(id(p))
+            if ent is None or ent[0]() is not p:
+                continue
+            cout, cin, taps = _wdims(p) if p.dim() >= 2 else (0, 0, 0)
+            if taps < 1 or taps > 32 or p.dim() == 5:
+                continue
+            for mode in (10, 11):
+                if mode in ent[1]:
+                    out.append((p, mode - 10, ent[1][mode][1], cout, cin, taps, ent))
+        return out
+
+    def run(self):
+        ents = self._entries()
+        if not ents:
+            return
+        sig = tuple((id(p), m, t.data_ptr()) for p, m, t, *_ in ents)
+        if sig != self.sig:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            import numpy as np
+            rec = np.zeros((len(ents), 5), dtype=np.int64)      # 40-byte records: src, dst, (mode,Cout), (Cin,taps), (tile_begin,0)
+            tiles, mt = 0, 0
+            for i, (p, m, t, cout, cin, taps, _) in enumerate(ents):
+                n, k = (cout, cin) if m == 0 else (cin, cout)
+                rec[i, 0], rec[i, 1] = p.data_ptr(), t.data_ptr()
+                rec[i, 2] = m | (cout << 32)
+                rec[i, 3] = cin | (taps << 32)
+                rec[i, 4] = tiles
+                tiles += ((k + 31) // 32) * (((n + 31) // 32 * 32) // 8)
+                mt = max(mt, taps)
+            self.table = torch.from_numpy(rec).to(ents[0][0].device)
+            self.meta = (len(ents), tiles, mt)
+            self.sig = sig
+        nd, tiles, mt = self.meta
+        check(_lib.lib().vca_pack_weight_bf16_batch(self.table.data_ptr(), nd, tiles, mt, stream()), 'pack_batch')
+        for p, m, t, cout, cin, taps, ent in ents:
+            ent[1][m + 10] = (_wkey(p), t)
 
 
 def flatten_module(module):
@@ -1344,6 +1399,7 @@ def flatten_module(module):
         p._vca_epoch = epoch
         off += sz
     _flat_epoch[flat.data_ptr()] = epoch
+    _flat_params[flat.data_ptr()] = ps
     _param_epoch[0] += 1
     return flat, gflat
 
@@ -1360,6 +1416,8 @@ class FusedAdam:
         self.t_dev = torch.zeros(1, device=groups[0][0].device, dtype=torch.int32)   # graph-replayable step count
         self.state = [dict(m=torch.zeros_like(f), v=torch.zeros_like(f),
                            vmax=torch.zeros_like(f) if amsgrad else None) for f, _ in groups]
+        self.repack = [_RepackPlan(_flat_params[f.data_ptr()]) if f.data_ptr() in _flat_params else None
+                       for f, _ in groups]
 
     def zero_grad(self, set_to_none=False):
         for _, g in self.groups:
@@ -1378,3 +1436,7 @@ class FusedAdam:
                 ep[0] += 1
             else:
                 _param_epoch[0] += 1
+        if _precision[0] != 'fp32':
+            for plan in self.repack:
+                if plan is not None:
+                    plan.run()
