@@ -80,6 +80,16 @@ int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const float* src,
  * stays zeroed between uses (the gradient that autograd accumulates into nn.Parameter.grad, train.py:209,235). */
 int vca_unpack_wgrad_f32(int Cout, int Cin, int taps, float* dwpack, float* w_grad, float beta, int clear,
                          void* stream);
+/* vca_unpack_wgrad_f32 (beta = 1, clear = 1) for many workspaces in one launch: the weight gradients of a whole
+ * backward pass are left in per-parameter workspaces and added to the parameters' gradients together.  table: ndesc
+ * records in DEVICE memory sorted by tile_begin = running sum of ceil(Cin*taps/64) * ceil(roundup(Cout,4)/32);
+ * total_tiles = that sum over all records. */
+typedef struct vca_unpack_desc {
+  float* src;    /* [taps][Cin][Cout4] workspace */
+  float* dst;    /* [Cout][Cin][taps] gradient */
+  int Cout, Cin, taps, tile_begin;
+} vca_unpack_desc;
+int vca_unpack_wgrad_batch_f32(const vca_unpack_desc* table, int ndesc, int total_tiles, void* stream);
 
 /* Split-bf16 variant of vca_conv_fwd_f32 on v_mfma_f32_32x32x16_bf16 (2-D maps, Cin > 1; used for the
  * forward pass and, with the input-gradient descriptor, for the input gradient).  nsplit = 3: every fp32

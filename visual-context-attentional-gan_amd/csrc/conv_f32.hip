@@ -486,12 +486,12 @@ __global__ void pack_weight_kernel(int mode, int Cout, int Cin, int taps, const 
 // dst[co][ci][t] = beta*dst + src[t][ci][co4], and src is cleared behind the read: the weight-gradient kernels
 // accumulate into src with atomics, so a workspace that is always handed back zeroed never needs a fill launch.
 // A workgroup transposes 32 co x 64 (ci,t) entries through LDS so both the reads and the writes are coalesced.
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(int Cout, int Cin, int taps, float* __restrict__ src,
-                                                           float* __restrict__ dst, float beta, int clear) {
-  __shared__ float tile[64][33];
+__device__ __forceinline__ void unpack_wgrad_tile(int Cout, int Cin, int taps, float* __restrict__ src,
+                                                  float* __restrict__ dst, float beta, int clear, int etile,
+                                                  int cotile, float (*tile)[33]) {
   const int Cout4 = (Cout + 3) & ~3;
   const int E = Cin * taps;
-  const int e0 = blockIdx.x * 64, co0 = blockIdx.y * 32;
+  const int e0 = etile * 64, co0 = cotile * 32;
   const int tid = threadIdx.x;
   {
     const int cl = tid & 31, co = co0 + cl;
@@ -521,6 +521,30 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(int Cout, int Cin, in
       *pd = beta == 0.f ? v : beta * *pd + v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(int Cout, int Cin, int taps, float* __restrict__ src,
+                                                           float* __restrict__ dst, float beta, int clear) {
+  __shared__ float tile[64][33];
+  unpack_wgrad_tile(Cout, Cin, taps, src, dst, beta, clear, blockIdx.x, blockIdx.y, tile);
+}
+
+// The same for every weight-gradient workspace of a backward pass in one launch: descriptors with a running first
+// tile; a workgroup finds its descriptor by bisection.  Always dst += src and src cleared.
+__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const vca_unpack_desc* __restrict__ table, int ndesc) {
+  __shared__ float tile[64][33];
+  const int t = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile_begin <= t) lo = mid;
+    else hi = mid - 1;
+  }
+  const vca_unpack_desc d = table[lo];
+  const int local = t - d.tile_begin;
+  const int et = (d.Cin * d.taps + 63) / 64, ct = (((d.Cout + 3) & ~3) + 31) / 32;
+  if (local >= et * ct) return;
+  unpack_wgrad_tile(d.Cout, d.Cin, d.taps, d.src, d.dst, 1.0f, 1, local % et, local / et, tile);
 }
 
 bool desc_ok(const vca_conv_desc* d) {
@@ -634,6 +658,12 @@ extern "C" int vca_pack_weight_f32(int mode, int Cout, int Cin, int taps, const 
   const int thr = 256;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + thr - 1) / thr)), dim3(thr), 0,
                      (hipStream_t)stream, mode, Cout, Cin, taps, src, dst, beta);
+  return vca_launch_status();
+}
+
+extern "C" int vca_unpack_wgrad_batch_f32(const vca_unpack_desc* table, int ndesc, int total_tiles, void* stream) {
+  VCA_CHECK_ARG(table && ndesc > 0 && total_tiles > 0);
+  hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, ndesc);
   return vca_launch_status();
 }
 

@@ -196,10 +196,16 @@ _wgrad_ws = {}          # (device, shape) -> [taps][Cin][Cout4] workspace, zero 
 _direct_grad = [False]  # set by direct_param_grad()
 
 
+_wgrad_own = {}         # (grad data_ptr, shape) -> that parameter's own zero-between-uses workspace
+_wgrad_pending = {}     # (grad data_ptr, shape) -> (workspace, grad tensor, cout, cin, taps), filled during a backward
+_unpack_tables = {}     # signature of a pending set -> (device table, ndesc, tiles)
+
+
 class direct_param_grad:
     """While active, the weight gradient of a leaf parameter whose .grad is already allocated (the flat gradient
-    buffers of flatten_module) is accumulated straight into it by the unpack kernel instead of being returned to
-    autograd, which would materialise it and add it with one more kernel per parameter."""
+    buffers of flatten_module) is not returned to autograd (which would materialise it and add it with one more
+    kernel per parameter): the weight-gradient kernels leave it in a workspace owned by that parameter, and on exit
+    all workspaces are transposed and added into the gradients by one launch."""
 
     def __enter__(self):
         self.prev = _direct_grad[0]
@@ -207,6 +213,34 @@ class direct_param_grad:
 
     def __exit__(self, *exc):
         _direct_grad[0] = self.prev
+        if not self.prev:
+            _flush_wgrads()
+
+
+def _flush_wgrads():
+    if not _wgrad_pending:
+        return
+    keys = sorted(_wgrad_pending)
+    ents = [_wgrad_pending[k] for k in keys]
+    _wgrad_pending.clear()
+    L = _lib.lib()
+    sig = tuple(keys)
+    tab = _unpack_tables.get(sig)
+    if tab is None and not torch.cuda.is_current_stream_capturing():
+        import numpy as np
+        rec = np.zeros((len(ents), 4), dtype=np.int64)     # 32-byte records: src, dst, (Cout,Cin), (taps,tile_begin)
+        tiles = 0
+        for i, (ws, g, cout, cin, taps) in enumerate(ents):
+            rec[i, 0], rec[i, 1] = ws.data_ptr(), g.data_ptr()
+            rec[i, 2] = cout | (cin << 32)
+            rec[i, 3] = taps | (tiles << 32)
+            tiles += ((cin * taps + 63) // 64) * ((((cout + 3) // 4 * 4) + 31) // 32)
+        tab = _unpack_tables[sig] = (torch.from_numpy(rec).to(ents[0][0].device), len(ents), tiles)
+    if tab is not None:
+        check(L.vca_unpack_wgrad_batch_f32(tab[0].data_ptr(), tab[1], tab[2], stream()), 'unpack_batch')
+        return
+    for ws, g, cout, cin, taps in ents:      # a new set of gradients met while capturing: one launch each
+        check(L.vca_unpack_wgrad_f32(cout, cin, taps, ptr(ws), ptr(g), 1.0, 1, stream()), 'unpack_wgrad')
 
 
 _inputs_only = [False]  # set by input_grads_only()
@@ -262,10 +296,20 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None):
     sink and None is returned."""
     cout, cin, taps = cfg.cout, cfg.cin, cfg.kd * cfg.kh * cfg.kw
     shape = (taps, cin, (cout + 3) // 4 * 4)
-    key = (x.device, shape)
-    dwp = _wgrad_ws.get(key)
-    if dwp is None:
-        dwp = _wgrad_ws[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
+    deferred = sink is not None and _direct_grad[0]
+    if deferred:
+        # the parameter's own workspace: contributions of several backward nodes accumulate in it and it is
+        # unpacked once, together with all the others, when the backward pass is over
+        key = (sink.data_ptr(), shape)
+        dwp = _wgrad_own.get(key)
+        if dwp is None:
+            dwp = _wgrad_own[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
+        _wgrad_pending[key] = (dwp, sink, cout, cin, taps)
+    else:
+        key = (x.device, shape)
+        dwp = _wgrad_ws.get(key)
+        if dwp is None:
+            dwp = _wgrad_ws[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
     ns = _nsplit(True)
     if ns and cin > 1 and cfg.kd == 1 and taps <= 32:
         check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
@@ -273,6 +317,8 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None):
     else:
         check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
               'conv_wgrad')
+    if deferred:
+        return None
     gw = sink if sink is not None else torch.empty(cfg.pshape, device=x.device, dtype=torch.float32)
     # the unpack kernel zeroes the workspace behind its reads
     check(_lib.lib().vca_unpack_wgrad_f32(cout, cin, taps, ptr(dwp), ptr(gw), 1.0 if sink is not None else 0.0, 1,
