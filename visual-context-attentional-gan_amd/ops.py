@@ -27,6 +27,43 @@ _param_epoch = [0]   # bumped whenever parameters are rewritten behind autograd'
 _pack_cache = {}     # id(parameter) -> (weakref, {mode: (version, packed tensor)})
 
 
+# Small zero-initialised scratch (batch-norm partial sums, convolution statistics): inside a training step they are
+# carved from one arena that a single fill clears at the start of the step, instead of one fill launch each.
+_arena = {}          # device -> [buffer, offset, active, used by the previous step]
+_ARENA_FLOATS = 8 << 20
+
+
+def step_begin(device):
+    """Start of a training step: clear the part of the scratch arena the previous step used and hand it out again."""
+    a = _arena.get(device)
+    if a is None:
+        a = _arena[device] = [torch.zeros(_ARENA_FLOATS, device=device, dtype=torch.float32), 0, False, 0]
+    a[3] = max(a[3], a[1])
+    if a[3]:
+        a[0][:a[3]].zero_()
+    a[1], a[2] = 0, True
+
+
+def step_end(device):
+    a = _arena.get(device)
+    if a is not None:
+        a[3] = max(a[3], a[1])
+        a[2] = False
+
+
+def _zeros(shape, device):
+    """Zero-filled fp32 scratch that is consumed within the current forward/backward call."""
+    a = _arena.get(device)
+    n = 1
+    for d in shape:
+        n *= d
+    if a is not None and a[2] and a[1] + n <= _ARENA_FLOATS:
+        off = a[1]
+        a[1] = off + (n + 63) // 64 * 64
+        return a[0][off:off + n].view(shape)
+    return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
 def _wkey(w):
     """Validity key of a packed copy of w: autograd's version counter, the global epoch, and the epoch of the flat
     buffer the parameter lives in (bumped by the fused Adam step that rewrites exactly that buffer, so one
@@ -340,7 +377,7 @@ class ConvStatsFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.save_for_backward(x, w)
-        stats = torch.zeros((2, cfg.cout), device=x.device, dtype=torch.float32)
+        stats = _zeros((2, cfg.cout), x.device)
         y = _conv_fwd_raw(_c(x), w, bias, cfg, stats)
         ctx.mark_non_differentiable(stats)
         return y, stats
@@ -491,7 +528,7 @@ class StemConvFn(torch.autograd.Function):
                     _pack_cache[k2] = ent
                 ent[1][key] = (_wkey(w), wp)
         y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
-        stats = torch.zeros((2, 64), device=x.device, dtype=torch.float32)
+        stats = _zeros((2, 64), x.device)
         check(L.vca_stem_fwd_bf16(_nsplit(), B, T, H, W, ptr(x), wp.data_ptr(), ptr(y), ptr(stats), stream()),
               'stem_fwd')
         ctx.save_for_backward(x, w)
@@ -583,7 +620,7 @@ class BnActFn(torch.autograd.Function):
         P, C = _pc(x)
         gy = _c(gy)
         need_sums = coef is not None or act == ACT_PRELU
-        sums = torch.zeros((16, 3, C), device=x.device, dtype=torch.float32) if need_sums else None   # VCA_BN_SLOTS
+        sums = _zeros((16, 3, C), x.device) if need_sums else None   # VCA_BN_SLOTS
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
         mean, invstd, sc, sh = (coef[0], coef[1], coef[2], coef[3]) if coef is not None else (None,) * 4
@@ -605,7 +642,7 @@ def _bn_coef(x, bn, stats=None):
     if bn.training or bn.running_mean is None:
         pivot = None
         if stats is None:
-            sums = torch.zeros((16, 2, C), device=x.device, dtype=torch.float32)   # VCA_BN_SLOTS partial buffers
+            sums = _zeros((16, 2, C), x.device)   # VCA_BN_SLOTS partial buffers
             pivot = _c(x.detach())
             check(L.vca_colstats_f32(P, C, ptr(pivot), ptr(sums), stream()), 'colstats')
         elif isinstance(stats, BnStats):
@@ -647,7 +684,7 @@ def bn_act_parts(parts, bn, act=None):
             P, Ci = _pc(x)
             assert P * rep == n, (P, rep, n)
             xs = _c(x.detach())
-            sm = torch.zeros((16, 2, Ci), device=dev, dtype=torch.float32)   # VCA_BN_SLOTS partial buffers
+            sm = _zeros((16, 2, Ci), dev)   # VCA_BN_SLOTS partial buffers
             check(L.vca_colstats_f32(P, Ci, ptr(xs), ptr(sm), stream()), 'colstats')
             sums.append(sm[0] * float(rep) if rep != 1 else sm[0])
             pivots.append(xs.reshape(P, Ci)[0])
@@ -900,7 +937,7 @@ class BnActPool3Fn(torch.autograd.Function):
         L = _lib.lib()
         g = torch.empty_like(x)
         check(L.vca_maxpool3s2_bwd_f32(n, h, w, c, ptr(_c(gy)), idx.data_ptr(), ptr(g), stream()), 'maxpool_bwd')
-        sums = torch.zeros((16, 3, c), device=x.device, dtype=torch.float32)   # VCA_BN_SLOTS
+        sums = _zeros((16, 3, c), x.device)   # VCA_BN_SLOTS
         gx = torch.empty_like(x)
         check(L.vca_affine_act_bwd_f32(n * h * w, c, ptr(g), ptr(x), ptr(coef[2]), ptr(coef[3]), ptr(alpha), None,
                                        ptr(coef[0]), ptr(coef[1]), act, slope, 1.0, 1 if train else 0, ptr(sums),

@@ -81,6 +81,7 @@ class GanStep:
     def d_phase(self, mel, spec, vid, vid_len, noise=None):
         """Forward of the generator side, discriminator losses and their backward (train.py:170-210)."""
         m = self.m
+        ops.step_begin(mel.device)
         self._zero(G_NAMES)
         ops.rng_advance(mel.device)
         mel1 = ops.mel_down(mel, 4)          # F.interpolate(mel, scale_factor=0.25, mode='bilinear'), train.py:170
@@ -155,6 +156,7 @@ class GanStep:
     def finish(self):
         """g_optimizer.step() (train.py:236); returns the step's losses and outputs."""
         self.g_opt.step()
+        ops.step_end(self._st['g3'].device)
         out, self._st = self._st, None
         return out
 
