@@ -224,6 +224,14 @@ int vca_gru_cell_bwd2_f32(int B, int H, int dout_stride, const float* dout0, con
                           const float* dha1, const float* dhb0, const float* dhb1, const float* save0,
                           const float* save1, const float* hp0, const float* hp1, float* dgi0, float* dgi1,
                           float* dgh0, float* dgh1, float* dhd0, float* dhd1, void* stream);
+/* One step of the GRU backward recurrence (visual_front.py:20 backward) for both directions in one launch: the
+ * recurrent product dh = d_gh(previous step) . W_hh (w_i: vca_pack_weight_bf16 mode 1 of the (3H, H) weight) with
+ * the gate arithmetic of vca_gru_cell_bwd2_f32 applied in its epilogue (dh_a is the product itself). */
+int vca_gru_bwd_step_bf16(int nsplit, int B, int H, const float* dgh_prev0, const float* dgh_prev1, const void* w0,
+                          const void* w1, int dout_stride, const float* dout0, const float* dout1, const float* dhb0,
+                          const float* dhb1, const float* save0, const float* save1, const float* hp0,
+                          const float* hp1, float* dgi0, float* dgi1, float* dgh0, float* dgh1, float* dhd0,
+                          float* dhd1, void* stream);
 
 /* Latency-oriented GEMM for the recurrent products: y_i[M][N] = x_i[M][K] . W_i^T (+ bias_i) for nprob = 1 or 2
  * independent problems of the same shape in one launch (the two directions of a bidirectional layer).

@@ -172,8 +172,14 @@ struct SkinnyArgs {
   const float* bias[2];
   float* y[2];
   int M, N, K, npad, nsplit;
+  // optional epilogue (EP): the product is dh of a GRU backward step (N = H hidden units) and the gate arithmetic
+  // of that step (gru_cell_bwd2_kernel) is applied to it in place of the store
+  const float* dout[2]; const float* dh_b[2]; const float* save[2]; const float* h_prev[2];
+  float* d_gi[2]; float* d_gh[2]; float* dh_direct[2];
+  int dout_stride;
 };
 
+template <bool EP>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
   __shared__ float red[4][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
@@ -246,8 +252,26 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const int m = m0 + r, n = n0 + c;
     if (m < a.M && n < a.N) {
       float s = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
-      if (a.bias[z]) s += a.bias[z][n];
-      a.y[z][(size_t)m * a.N + n] = s;
+      if (!EP) {
+        if (a.bias[z]) s += a.bias[z][n];
+        a.y[z][(size_t)m * a.N + n] = s;
+      } else {
+        const int H = a.N;
+        const size_t e = (size_t)m * H + n;
+        float dh = a.dout[z][(size_t)m * a.dout_stride + n] + s;
+        if (a.dh_b[z]) dh += a.dh_b[z][e];
+        const float* sv = a.save[z] + (size_t)m * 4 * H;
+        const float rg = sv[n], zg = sv[H + n], ng = sv[2 * H + n], hn = sv[3 * H + n];
+        const float hp = a.h_prev[z] ? a.h_prev[z][e] : 0.f;
+        const float dn = dh * (1.f - zg) * (1.f - ng * ng);
+        const float dz = dh * (hp - ng) * zg * (1.f - zg);
+        const float dr = dn * hn * rg * (1.f - rg);
+        float* gi = a.d_gi[z] + (size_t)m * 3 * H;
+        float* gh = a.d_gh[z] + (size_t)m * 3 * H;
+        gi[n] = dr; gi[H + n] = dz; gi[2 * H + n] = dn;
+        gh[n] = dr; gh[H + n] = dz; gh[2 * H + n] = dn * rg;
+        a.dh_direct[z][e] = dh * zg;
+      }
     }
   }
 }
@@ -265,7 +289,28 @@ extern "C" int vca_skinny_gemm_bf16(int nsplit, int nprob, int M, int N, int K, 
   a.bias[0] = b0; a.bias[1] = b1;
   a.y[0] = y0; a.y[1] = y1;
   a.M = M; a.N = N; a.K = K; a.npad = (N + 31) / 32 * 32; a.nsplit = nsplit;
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(256), 0, (hipStream_t)stream,
-                     a);
+  hipLaunchKernelGGL(skinny_gemm_kernel<false>, dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return vca_launch_status();
+}
+
+extern "C" int vca_gru_bwd_step_bf16(int nsplit, int B, int H, const float* dgh_prev0, const float* dgh_prev1,
+                                     const void* w0, const void* w1, int dout_stride, const float* dout0,
+                                     const float* dout1, const float* dhb0, const float* dhb1, const float* save0,
+                                     const float* save1, const float* hp0, const float* hp1, float* dgi0, float* dgi1,
+                                     float* dgh0, float* dgh1, float* dhd0, float* dhd1, void* stream) {
+  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && H > 0 && dgh_prev0 && dgh_prev1 && w0 && w1);
+  VCA_CHECK_ARG(dout0 && dout1 && save0 && save1 && dgi0 && dgi1 && dgh0 && dgh1 && dhd0 && dhd1 && dout_stride >= H);
+  SkinnyArgs a;
+  a.x[0] = dgh_prev0; a.x[1] = dgh_prev1;
+  a.w[0] = reinterpret_cast<const unsigned char*>(w0); a.w[1] = reinterpret_cast<const unsigned char*>(w1);
+  a.bias[0] = a.bias[1] = nullptr;
+  a.y[0] = a.y[1] = nullptr;
+  a.M = B; a.N = H; a.K = 3 * H; a.npad = (H + 31) / 32 * 32; a.nsplit = nsplit;
+  a.dout[0] = dout0; a.dout[1] = dout1; a.dh_b[0] = dhb0; a.dh_b[1] = dhb1; a.save[0] = save0; a.save[1] = save1;
+  a.h_prev[0] = hp0; a.h_prev[1] = hp1; a.d_gi[0] = dgi0; a.d_gi[1] = dgi1; a.d_gh[0] = dgh0; a.d_gh[1] = dgh1;
+  a.dh_direct[0] = dhd0; a.dh_direct[1] = dhd1; a.dout_stride = dout_stride;
+  hipLaunchKernelGGL(skinny_gemm_kernel<true>, dim3((H + 31) / 32, (B + 31) / 32, 2), dim3(256), 0,
+                     (hipStream_t)stream, a);
   return vca_launch_status();
 }

@@ -1261,18 +1261,32 @@ class GruLayerFn(torch.autograd.Function):
         d_gh = [torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32) for _ in range(2)]
         w_hh = [wts[1], wts[5]]
         dh_gemm, dh_dir = [None, None], [None, None]
+        ns = _nsplit()
         for s in range(T):
-            ts = (T - 1 - s, s)
-            t0, t1 = ts
+            t0, t1 = T - 1 - s, s
             nd = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
-            check(L.vca_gru_cell_bwd2_f32(B, H, 2 * H, dout[t0].data_ptr(), dout[t1].data_ptr() + 4 * H,
-                                          ptr(dh_gemm[0]), ptr(dh_gemm[1]), ptr(dh_dir[0]), ptr(dh_dir[1]),
-                                          ptr(save[0][t0]), ptr(save[1][t1]), ptr(hprev[0][t0]), ptr(hprev[1][t1]),
-                                          ptr(d_gi[0][t0]), ptr(d_gi[1][t1]), ptr(d_gh[0][t0]), ptr(d_gh[1][t1]),
-                                          ptr(nd[0]), ptr(nd[1]), stream()), 'gru_cell_bwd2')
+            if s > 0 and ns:
+                # recurrent product of the previous step's gate gradients with the gate arithmetic of this step in
+                # its epilogue: one launch per time step for both directions
+                p0, p1 = T - s, s - 1
+                packs = [_pack(w, 11) for w in w_hh]
+                check(L.vca_gru_bwd_step_bf16(ns, B, H, ptr(d_gh[0][p0]), ptr(d_gh[1][p1]), packs[0].data_ptr(),
+                                              packs[1].data_ptr(), 2 * H, dout[t0].data_ptr(),
+                                              dout[t1].data_ptr() + 4 * H, ptr(dh_dir[0]), ptr(dh_dir[1]),
+                                              ptr(save[0][t0]), ptr(save[1][t1]), ptr(hprev[0][t0]),
+                                              ptr(hprev[1][t1]), ptr(d_gi[0][t0]), ptr(d_gi[1][t1]),
+                                              ptr(d_gh[0][t0]), ptr(d_gh[1][t1]), ptr(nd[0]), ptr(nd[1]), stream()),
+                      'gru_bwd_step')
+            else:
+                if s > 0:
+                    dh_gemm = _rec_gemm([d_gh[0][T - s], d_gh[1][s - 1]], w_hh, [None, None], 1)
+                check(L.vca_gru_cell_bwd2_f32(B, H, 2 * H, dout[t0].data_ptr(), dout[t1].data_ptr() + 4 * H,
+                                              ptr(dh_gemm[0]), ptr(dh_gemm[1]), ptr(dh_dir[0]), ptr(dh_dir[1]),
+                                              ptr(save[0][t0]), ptr(save[1][t1]), ptr(hprev[0][t0]),
+                                              ptr(hprev[1][t1]), ptr(d_gi[0][t0]), ptr(d_gi[1][t1]),
+                                              ptr(d_gh[0][t0]), ptr(d_gh[1][t1]), ptr(nd[0]), ptr(nd[1]), stream()),
+                      'gru_cell_bwd2')
             dh_dir = nd
-            if s + 1 < T:
-                dh_gemm = _rec_gemm([d_gh[0][ts[0]], d_gh[1][ts[1]]], w_hh, [None, None], 1)
         dx = None
         grads = []
         for d in range(2):
