@@ -179,15 +179,15 @@ struct SkinnyArgs {
   int dout_stride;
 };
 
-template <bool EP>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
-  __shared__ float red[4][32][33];
+template <bool EP, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
+  __shared__ float red[NW][32][33];   // NW waves split the reduction (8 for the deep K = 3H of the backward step)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int z = blockIdx.z, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const float* x = a.x[z];
   const unsigned char* w = a.w[z];
   const int nks = (a.K + 15) / 16;
-  const int per = (nks + 3) / 4;
+  const int per = (nks + NW - 1) / NW;
   const int ks_beg = wave * per, ks_end = min(nks, ks_beg + per);
   f32x16 acc;
 #pragma unroll
@@ -247,11 +247,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
   __syncthreads();
-  for (int i = tid; i < 32 * 32; i += 256) {
+  for (int i = tid; i < 32 * 32; i += 64 * NW) {
     const int r = i >> 5, c = i & 31;
     const int m = m0 + r, n = n0 + c;
     if (m < a.M && n < a.N) {
-      float s = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
+      float s = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) s += red[w8][r][c];
       if (!EP) {
         if (a.bias[z]) s += a.bias[z][n];
         a.y[z][(size_t)m * a.N + n] = s;
@@ -289,8 +291,12 @@ extern "C" int vca_skinny_gemm_bf16(int nsplit, int nprob, int M, int N, int K, 
   a.bias[0] = b0; a.bias[1] = b1;
   a.y[0] = y0; a.y[1] = y1;
   a.M = M; a.N = N; a.K = K; a.npad = (N + 31) / 32 * 32; a.nsplit = nsplit;
-  hipLaunchKernelGGL(skinny_gemm_kernel<false>, dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (K >= 1024)
+    hipLaunchKernelGGL((skinny_gemm_kernel<false, 8>), dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(512), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((skinny_gemm_kernel<false, 4>), dim3((N + 31) / 32, (M + 31) / 32, nprob), dim3(256), 0,
+                       (hipStream_t)stream, a);
   return vca_launch_status();
 }
 
@@ -310,7 +316,7 @@ extern "C" int vca_gru_bwd_step_bf16(int nsplit, int B, int H, const float* dgh_
   a.dout[0] = dout0; a.dout[1] = dout1; a.dh_b[0] = dhb0; a.dh_b[1] = dhb1; a.save[0] = save0; a.save[1] = save1;
   a.h_prev[0] = hp0; a.h_prev[1] = hp1; a.d_gi[0] = dgi0; a.d_gi[1] = dgi1; a.d_gh[0] = dgh0; a.d_gh[1] = dgh1;
   a.dh_direct[0] = dhd0; a.dh_direct[1] = dhd1; a.dout_stride = dout_stride;
-  hipLaunchKernelGGL(skinny_gemm_kernel<true>, dim3((H + 31) / 32, (B + 31) / 32, 2), dim3(256), 0,
+  hipLaunchKernelGGL((skinny_gemm_kernel<true, 8>), dim3((H + 31) / 32, (B + 31) / 32, 2), dim3(512), 0,
                      (hipStream_t)stream, a);
   return vca_launch_status();
 }
