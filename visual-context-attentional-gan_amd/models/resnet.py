@@ -39,7 +39,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y, st = ops.conv2d(x, self.conv1.weight, None, self.stride, 1, want_stats=True)
+        # x also feeds the shortcut: it is taken from the convolution's alias output so that the shortcut's gradient
+        # is added inside conv1's input-gradient kernel
+        y, st, x = ops.conv2d_skip(x, self.conv1.weight, self.stride, 1)
         y = ops.bn_act(y, self.bn1, self.relu1, stats=st)
         y, st = ops.conv2d(y, self.conv2.weight, None, 1, 1, want_stats=True)
         if self.downsample is not None:

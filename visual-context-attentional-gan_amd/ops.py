@@ -212,20 +212,26 @@ def _conv_fwd_raw(x, w, bias, cfg, stats=None):
     return y
 
 
-def _conv_dgrad_raw(gy, w, cfg):
+def _conv_dgrad_raw(gy, w, cfg, res=None):
+    """Input gradient; `res` (a tensor of the input's shape) is added in the kernel epilogue."""
     he, we = cfg.hin << cfg.ups, cfg.win << cfg.ups
     gx = torch.empty((cfg.n, he, we, cfg.cin), device=gy.device, dtype=torch.float32)
     d = cfg.dgrad_desc()
     ns = _nsplit(True)
+    fuse = res is not None and not cfg.ups
+    r = _c(res) if fuse else None
     if ns and cfg.cout > 1:
-        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, None,
+        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, ptr(r),
                                            ptr(gx), None, stream()), 'conv_dgrad_bf16')
     else:
-        check(_lib.lib().vca_conv_fwd_f32(d, ptr(gy), ptr(_pack(w, 1)), None, None, None, None, None, ptr(gx), None,
+        check(_lib.lib().vca_conv_fwd_f32(d, ptr(gy), ptr(_pack(w, 1)), None, None, None, None, ptr(r), ptr(gx), None,
                                           stream()), 'conv_dgrad')
     if cfg.ups:
         gx = gx.view(cfg.n, cfg.hin, 2, cfg.win, 2, cfg.cin).sum((2, 4))
-    return gx.view(cfg.xshape)
+    gx = gx.view(cfg.xshape)
+    if res is not None and not fuse:
+        gx = gx + res
+    return gx
 
 
 _wgrad_ws = {}          # (device, shape) -> [taps][Cin][Cout4] workspace, zero whenever no kernel is using it; shared by
@@ -392,6 +398,44 @@ class ConvStatsFn(torch.autograd.Function):
         gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
         gb = _bias_grad(gy, ctx.bias_ref, cfg.cout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
+
+
+class ConvStatsSkipFn(torch.autograd.Function):
+    """ConvStatsFn (no bias) that also hands its input back as a third output.  A block whose input feeds both this
+    convolution and a shortcut takes the shortcut from that output: autograd then delivers the shortcut's gradient
+    to this node together with the convolution's, and the input-gradient kernel adds it in its epilogue instead of
+    autograd adding two full-size tensors afterwards (resnet.py:53-66: `out += residual`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, cfg):
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, w)
+        stats = _zeros((2, cfg.cout), x.device)
+        y = _conv_fwd_raw(_c(x), w, None, cfg, stats)
+        ctx.mark_non_differentiable(stats)
+        return y, stats, x.view_as(x)
+
+    @staticmethod
+    @once
+    def backward(ctx, gy, _gs, gskip):
+        x, w = ctx.saved_tensors
+        cfg = ctx.cfg
+        gy = _c(gy)
+        gx = _conv_dgrad_raw(gy, w, cfg, gskip) if ctx.needs_input_grad[0] else None
+        gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def conv2d_skip(x, w, stride=1, pad=0):
+    """Bias-free conv2d with statistics that also returns an alias of x for the block's shortcut branch:
+    (y, BnStats, x_alias)."""
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    cfg = ConvCfg(w.shape, x.shape, stride, pad, 0)
+    if cfg.cin > 1:
+        y, sums, xa = ConvStatsSkipFn.apply(x, w, cfg)
+        return y, BnStats(sums, None), xa
+    y, st = conv2d(x, w, None, stride, pad, want_stats=True)
+    return y, st, x
 
 
 class ConvFn(torch.autograd.Function):
