@@ -3,10 +3,13 @@
 //
 // One persistent workgroup (8 waves) walks patches of 16x16 output pixels of one frame.  The packed weights (hi/lo bf16,
 // [64][35 (kt,kh) rows x 8 kw slots], 74 KiB) are loaded into LDS once per workgroup; per patch the fp32 input halo
-// (5 frames x 37 rows x 40 columns) is prefetched into registers under the previous patch's MFMAs.  The reduction index is laid out as
+// (5 frames x 37 rows x 40 columns) is prefetched into registers under the previous patch's MFMAs and split into
+// hi/lo bf16 ONCE when it is written to LDS (each halo element is used by up to 64 (pixel, tap) pairs; converting
+// inside the MFMA loop cost a fifth of the kernel's VALU instructions).  The reduction index is laid out as
 // (kt, kh, kw') with kw' = kw + 1 in 0..7 (slot 0 has zero weight), so the 8 reduction elements one MFMA lane
-// supplies are 8 CONTIGUOUS floats of a halo row (x = 2*ox - 4 + kw'): four 8-byte LDS reads, split into hi/lo
-// bf16 in registers - no im2col image is ever materialised.  Per-channel sum / sum-of-squares of the outputs (for
+// supplies are 8 CONTIGUOUS values of a halo row (x = 2*ox - 4 + kw'): two 8-byte LDS reads per hi and lo image.
+// The row offset 2*tx is only 4-byte aligned for odd tx, so every image is kept twice, the second copy shifted by
+// two elements: even tx read copy 0, odd tx copy 1, both 8-byte aligned.  No im2col image is ever materialised.  Per-channel sum / sum-of-squares of the outputs (for
 // the following train-mode BatchNorm3d, visual_front.py:12) are accumulated in registers across the walk and added
 // to `stats` once per workgroup.
 #include "common.h"
@@ -23,7 +26,9 @@ constexpr int PH = 16, PW = 16;      // output patch (8 waves x 32 pixels)
 constexpr int NTHR = 512;
 constexpr int HR = 2 * (PH - 1) + KH;  // 37 halo rows
 constexpr int HC = 40;               // halo columns (2*15 + 7 + 1 = 38, padded)
-constexpr int HALO = KT * HR * HC;   // 7400 floats
+constexpr int HALO = KT * HR * HC;   // 7400 elements
+constexpr int HC2 = 44;              // bf16 row pitch of the LDS images (40 columns + 2 shift, multiple of 4)
+constexpr int HIMG = KT * HR * HC2;  // elements of one LDS halo image
 
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ dst) {
   // dst[2][64][WROW]: hi image then lo image
@@ -46,7 +51,9 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* w_hi = reinterpret_cast<__bf16*>(smem);
   __bf16* w_lo = w_hi + CO * WROW;
-  float* halo = reinterpret_cast<float*>(smem + (NSPLIT == 3 ? 2 : 1) * CO * WROW * 2);
+  // halo images: [copy 0 | copy 1 (shifted by 2)] x [hi | lo]
+  __bf16* h_hi = reinterpret_cast<__bf16*>(smem + (NSPLIT == 3 ? 2 : 1) * CO * WROW * 2);
+  __bf16* h_lo = h_hi + 2 * HIMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
 
@@ -96,7 +103,20 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
     __syncthreads();   // previous patch fully consumed (and the weights are in place on the first pass)
 #pragma unroll
     for (int j = 0; j < NL; ++j)
-      if (plan[j] >= 0) halo[tid + NTHR * j] = hv[j];
+      if (plan[j] >= 0) {
+        const int pl = plan[j];
+        const int c = pl >> 16, rr = (pl & 255) * HR + ((pl >> 8) & 255);
+        const float v = hv[j];
+        const __bf16 h = (__bf16)v;
+        const int o = rr * HC2 + c;
+        h_hi[o] = h;
+        h_hi[HIMG + o + 2] = h;
+        if (NSPLIT == 3) {
+          const __bf16 l = (__bf16)(v - (float)h);
+          h_lo[o] = l;
+          h_lo[HIMG + o + 2] = l;
+        }
+      }
     __syncthreads();
     if (patch + (int)gridDim.x < npatch) issue(patch + gridDim.x);   // next halo streams in under the MFMAs
 
@@ -109,25 +129,17 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
 #pragma unroll 2
     for (int ks = 0; ks < KPAD / 16; ++ks) {
       const int q = ks * 2 + lh;            // (kt, kh) row this lane feeds
-      float v[8];
+      union { bf16x8 v; uint2 u[2]; } ah, al;
+      ah.u[0] = ah.u[1] = al.u[0] = al.u[1] = make_uint2(0u, 0u);
       if (q < NQ) {
         const int kt = q / KH, kh = q - kt * KH;
-        const float* src = halo + (kt * HR + 2 * ty + kh) * HC + 2 * tx;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 p = *reinterpret_cast<const float2*>(src + 2 * j);
-          v[2 * j] = p.x;
-          v[2 * j + 1] = p.y;
+        const int o = (tx & 1) * (HIMG + 2) + (kt * HR + 2 * ty + kh) * HC2 + 2 * tx;   // multiple of 4 elements
+        ah.u[0] = *reinterpret_cast<const uint2*>(h_hi + o);
+        ah.u[1] = *reinterpret_cast<const uint2*>(h_hi + o + 4);
+        if (NSPLIT == 3) {
+          al.u[0] = *reinterpret_cast<const uint2*>(h_lo + o);
+          al.u[1] = *reinterpret_cast<const uint2*>(h_lo + o + 4);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      }
-      bf16x8 ah, al;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ah[j] = (__bf16)v[j];
-        al[j] = (__bf16)(v[j] - (float)ah[j]);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -135,10 +147,10 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
         if (NSPLIT == 3) {
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl, acc[j], 0, 0, 0);
         }
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh, acc[j], 0, 0, 0);
       }
     }
 
@@ -186,7 +198,7 @@ extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const f
   const int tiles_y = (OH + PH - 1) / PH, tiles_x = (OW + PW - 1) / PW;
   const long long npatch = (long long)B * T * tiles_y * tiles_x;
   VCA_CHECK_ARG(npatch < (1ll << 31));
-  const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + HALO * sizeof(float);
+  const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + (size_t)4 * HIMG * 2 + 16;
   static bool attr = false;
   if (!attr) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<3>),
@@ -197,7 +209,7 @@ extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const f
     if (e2 != hipSuccess) return (int)e2;
     attr = true;
   }
-  int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo 29 KiB)
+  int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo images 64 KiB)
   if (grid > npatch) grid = (int)npatch;
   const __bf16* wp = reinterpret_cast<const __bf16*>(wpack);
   if (nsplit == 3)
