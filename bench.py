@@ -74,9 +74,11 @@ def roofline_probe(device, dtype):
 
 
 def cpu_baseline():
-    """The CPU oracle (restatement of the reference's PyTorch CPU path) on the host cores: B2 x T75 x 112x112."""
+    """The CPU oracle (restatement of the reference's PyTorch CPU path) on the host cores: B2 x T75 x 112x112,
+    one warm-up step and three timed ones.  Threads: every core this job may use (a one-GPU lease of the box owns 16
+    of the machine's cores, published through OMP_NUM_THREADS; os.cpu_count() there counts the whole machine)."""
     from oracle import cpu_ref, fixtures
-    cores = min(os.cpu_count() or 1, 16)
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '0') or 0) or (os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     m = cpu_ref.build_models()
     for k in m:
@@ -84,7 +86,7 @@ def cpu_baseline():
     opts = cpu_ref.build_optimizers(m)
     b = fixtures.make_batch(2, 75, 112, 1)
     cpu_ref.gan_step(m, opts, b, noise=b['noise'])
-    n = 2
+    n = 3
     t0 = time.time()
     for _ in range(n):
         cpu_ref.gan_step(m, opts, b, noise=b['noise'])
@@ -111,7 +113,17 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, (world, args.gpus)
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE is %d (launch N ranks with torch.distributed.run for --gpus N)'
+                 % (args.gpus, world))
+    # One process per GPU, each on a device of its own.  Two ranks on one device never get out of their first RCCL
+    # collective (both sit in the parameter broadcast until a watchdog kills them), so this is checked before the
+    # process group exists, where a wrong launch can still fail by itself with a message.
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    if ndev < local_world or local >= ndev:
+        sys.exit('bench.py: rank %d (local rank %d of %d) has no GPU of its own: %d device(s) visible; '
+                 'run with --gpus <= %d' % (rank, local, local_world, ndev, ndev))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     use_dist = world > 1 or os.environ.get('VCA_FORCE_EXCHANGE') == '1'   # the latter: one-rank RCCL rehearsal
@@ -141,7 +153,7 @@ def main():
     if not args.no_graph:
         try:
             graphed = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'],
-                                             data['noise'],
+                                             'device',
                                              segmented=True if os.environ.get('VCA_BENCH_SEGMENTED') == '1' else None)
         except Exception as e:       # capture not possible on this stack: fall back to eager launches
             print('graph capture failed, running eagerly: %r' % (e,), file=sys.stderr)
@@ -154,9 +166,9 @@ def main():
         out = None
         for _ in range(n):
             if graphed is not None:
-                out = graphed(data['mel'], data['spec'], data['vid'], None, data['noise'])
+                out = graphed(data['mel'], data['spec'], data['vid'])
             else:
-                out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise=data['noise'])
+                out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise='device')
             if trace_loss == 'sync':
                 torch.cuda.synchronize()
             elif trace_loss:
@@ -201,7 +213,9 @@ def main():
                        '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph'),
             'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                    'weights' % args.batch, 'global_batch': args.batch * world,
-                       'parallelism': 'dp%d' % world},
+                       'parallelism': 'dp%d' % world,
+                       'noise': 'decoder noise drawn afresh inside every timed step, on the device (counter-based '
+                                'generator) instead of torch.randn on the CPU + host-to-device copy'},
             'ref_algorithmic_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
             'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
         }
@@ -210,11 +224,11 @@ def main():
             # the same step with single-bf16 products in the plain input/weight gradients (forward and the R1 chain
             # stay split-bf16, so outputs keep fp32-level parity); reported beside `value`, never as `value`
             ops.set_precision('mixed')
-            g2 = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'], data['noise'])
+            g2 = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'], 'device')
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                g2(data['mel'], data['spec'], data['vid'], None, data['noise'])
+                g2(data['mel'], data['spec'], data['vid'])
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t1) / args.steps * 1e3
             ops.set_precision(args.precision)

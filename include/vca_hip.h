@@ -249,6 +249,36 @@ int vca_softplus_bwd_f32(int n, const float* x, float sign, float scale, const f
 int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, float* out, void* stream);
 int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
                    void* stream);
+/* All loss heads of one phase of the step in one launch (train.py:200-205 discriminator terms incl. the R1 squared
+ * norms of :188-194, :222-231 generator terms).  Head e computes v_e = scale * sum_i f(x_i[, y_i]) with
+ * f = softplus(sign*x) [kind 0, generator.py:363-366], |x - y| [1, nn.L1Loss], x^2 [2], x [3] and adds weight[k] * v_e
+ * into out[slot[k]] for each slot[k] >= 0 (slots < VCA_MAX_LOSS_SLOTS); `out` must be zero on entry.  The head table
+ * is host memory and is copied into the launch (nothing has to stay alive; a captured launch keeps its copy).  Head e
+ * owns the workgroups [block_begin_e, block_begin_e + ceil(n_e / vca_loss_head_chunk())); total_blocks is their sum.
+ * The backward launch writes gx_e[i] = (sum_k gout[slot[k]] * weight[k]) * scale * f'(x_i) for every head with
+ * gx != NULL. */
+#define VCA_MAX_LOSS_HEADS 24
+#define VCA_MAX_LOSS_SLOTS 16
+typedef struct vca_loss_head {
+  const float* x;
+  const float* y;
+  float* gx;
+  long long n;
+  int kind;
+  int block_begin;
+  float sign;
+  float scale;
+  int slot[3];
+  float weight[3];
+} vca_loss_head;
+typedef struct vca_loss_heads {
+  int nhead;
+  int total_blocks;
+  vca_loss_head h[VCA_MAX_LOSS_HEADS];
+} vca_loss_heads;
+int vca_loss_head_chunk(void);
+int vca_loss_heads_fwd_f32(const vca_loss_heads* heads, float* out, void* stream);
+int vca_loss_heads_bwd_f32(const vca_loss_heads* heads, const float* gout, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Data movement on channels-last maps.
  * ---------------------------------------------------------------------------------------------- */
@@ -284,6 +314,9 @@ int vca_window_mean_bwd_f32(int N, int H, int W, int C, int wh, int ww, const fl
 int vca_dropout_f32(long long n, const float* x, float p, unsigned long long seed, const int* step_dev, float* y,
                     unsigned char* mask, void* stream);
 int vca_dropout_bwd_f32(long long n, const float* gy, const unsigned char* mask, float p, float* gx, void* stream);
+/* n standard-normal draws from the same counter-based generator (the decoder noise of generator.py:248, drawn on the
+ * device instead of on the CPU generator + host-to-device copy); step_dev as in vca_dropout_f32. */
+int vca_randn_f32(long long n, unsigned long long seed, const int* step_dev, float* y, void* stream);
 /* F.interpolate(mel, scale_factor=1/factor, mode='bilinear') for factor 2 or 4 on [N][H][W] maps (train.py:170-171). */
 int vca_mel_down_f32(int N, int H, int W, int factor, const float* x, float* y, void* stream);
 
@@ -332,9 +365,12 @@ int vca_sync_cos_bwd_f32(int B, int T, int C, const float* v, const float* a, co
 
 /* torch.optim.Adam step (coupled L2 weight decay; amsgrad when vmax != NULL) over a flat buffer, n % 4 == 0
  * (train.py:82-83,211,237). `step` is the 1-based step count; when step_dev != NULL the count is read from that
- * device word instead (so the launch can be replayed from a captured HIP graph). */
+ * device word instead (so the launch can be replayed from a captured HIP graph), and when lr_dev != NULL the learning
+ * rate is read from that device float instead of `lr` (the MultiStepLR schedules of train.py:85-86 keep working under
+ * replay: the host rewrites the word between replays). */
 int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int step, const int* step_dev, void* stream);
+                 float beta2, float eps, float weight_decay, int step, const int* step_dev, const float* lr_dev,
+                 void* stream);
 
 #ifdef __cplusplus
 }

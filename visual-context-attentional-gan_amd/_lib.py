@@ -37,6 +37,19 @@ class ConvDesc(ctypes.Structure):
                  'pad_w', 'pad_d', 'dil', 'ups', 'act')] + [('slope', ctypes.c_float), ('out_scale', ctypes.c_float)]
 
 
+class LossHead(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('gx', ctypes.c_void_p), ('n', ctypes.c_longlong),
+                ('kind', ctypes.c_int), ('block_begin', ctypes.c_int), ('sign', ctypes.c_float),
+                ('scale', ctypes.c_float), ('slot', ctypes.c_int * 3), ('weight', ctypes.c_float * 3)]
+
+
+MAX_LOSS_HEADS, MAX_LOSS_SLOTS = 24, 16
+
+
+class LossHeads(ctypes.Structure):
+    _fields_ = [('nhead', ctypes.c_int), ('total_blocks', ctypes.c_int), ('h', LossHead * MAX_LOSS_HEADS)]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -90,6 +103,7 @@ _SIGS = {
     'vca_window_mean_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_window_mean_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_dropout_f32': ([_LL, _P, _F, ctypes.c_ulonglong, _P, _P, _P, _P], _I),
+    'vca_randn_f32': ([_LL, ctypes.c_ulonglong, _P, _P, _P], _I),
     'vca_dropout_bwd_f32': ([_LL, _P, _P, _F, _P, _P], _I),
     'vca_mel_down_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_reflect_pad_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),
@@ -99,7 +113,10 @@ _SIGS = {
     'vca_istft_finish_f32': ([_I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     'vca_deemphasis_clip_f32': ([_I, _I, _F, _P, _P, _P], _I),
     'vca_build_video_f32': ([_I] * 10 + [_F, _F] + [_P] * 11 + [_I, _P, _P], _I),
-    'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P], _I),
+    'vca_loss_head_chunk': ([], _I),
+    'vca_loss_heads_fwd_f32': ([_P, _P, _P], _I),
+    'vca_loss_heads_bwd_f32': ([_P, _P, _P], _I),
+    'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P, _P], _I),
 }
 
 _lib = None

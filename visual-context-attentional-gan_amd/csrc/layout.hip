@@ -103,6 +103,23 @@ __global__ __launch_bounds__(THR) void dropout_kernel(size_t n, const float* __r
   }
 }
 
+// Standard normal draws (Box-Muller on two uniforms of the counter-based generator; one pair per two outputs).
+// `step` as in dropout_kernel: replays of a captured graph draw fresh values.
+__global__ __launch_bounds__(THR) void randn_kernel(size_t n, unsigned long long seed, const int* __restrict__ step,
+                                                    float* __restrict__ y) {
+  const unsigned long long base = (unsigned long long)(step ? *step : 0) << 40;
+  const size_t pairs = (n + 1) >> 1;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < pairs; i += (size_t)gridDim.x * THR) {
+    const float u1 = 1.f - uniform01(seed, base + 2 * i);          // (0, 1]
+    const float u2 = uniform01(seed ^ 0xA5A5A5A5A5A5A5A5ull, base + 2 * i + 1);
+    const float r = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    y[2 * i] = r * cs;
+    if (2 * i + 1 < n) y[2 * i + 1] = r * sn;
+  }
+}
+
 __global__ __launch_bounds__(THR) void dropout_bwd_kernel(size_t n, const float* __restrict__ gy,
                                                           const unsigned char* __restrict__ mask, float scale,
                                                           float* __restrict__ gx) {
@@ -296,6 +313,13 @@ extern "C" int vca_dropout_f32(long long n, const float* x, float p, unsigned lo
   VCA_CHECK_ARG(n > 0 && x && y && mask && p >= 0.f && p < 1.f);
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)n)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, x, p,
                      seed, step_dev, y, mask);
+  return vca_launch_status();
+}
+
+extern "C" int vca_randn_f32(long long n, unsigned long long seed, const int* step_dev, float* y, void* stream) {
+  VCA_CHECK_ARG(n > 0 && y);
+  hipLaunchKernelGGL(randn_kernel, dim3(grid_for((size_t)(n + 1) / 2)), dim3(THR), 0, (hipStream_t)stream, (size_t)n,
+                     seed, step_dev, y);
   return vca_launch_status();
 }
 

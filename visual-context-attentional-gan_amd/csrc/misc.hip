@@ -67,8 +67,10 @@ __global__ __launch_bounds__(THR) void adam_kernel(size_t n, float* __restrict__
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, float lr, float b1, float b2,
                                                    float eps, float wd, float bc1, float bc2_sqrt,
-                                                   const int* __restrict__ step_dev) {
+                                                   const int* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev) {
   const size_t n4 = n >> 2;
+  if (lr_dev) lr = lr_dev[0];   // learning rate lives on the device: a replayed launch follows the schedule
   if (step_dev) {   // step count lives on the device (the launch is replayed from a HIP graph)
     const double t = (double)step_dev[0];
     bc1 = (float)(1.0 - pow((double)b1, t));
@@ -100,6 +102,74 @@ __global__ __launch_bounds__(THR) void adam_kernel(size_t n, float* __restrict__
     reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
     reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     if (vmax) reinterpret_cast<float4*>(vmax)[i] = make_float4(xx[0], xx[1], xx[2], xx[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// All loss heads of a phase in one launch (train.py:200-231: 18 softplus means, 4 L1 means, 3 R1 squared norms, the
+// sync-loss means and the weighted sums that combine them).  A head e reduces v_e = scale_e * sum_i f_e(x_i[, y_i])
+// and adds w_ek * v_e into up to three slots of the output vector (a reported term and the totals it is part of).
+// ---------------------------------------------------------------------------------------------------------------
+enum { HEAD_SOFTPLUS = 0, HEAD_L1 = 1, HEAD_SQSUM = 2, HEAD_SUM = 3 };
+constexpr int HEAD_CHUNK = 16384;   // elements one workgroup reduces
+
+// The head table travels in the kernel arguments (at most VCA_MAX_LOSS_HEADS heads): no device table to keep alive,
+// and a launch captured into a graph carries its own copy.
+__device__ __forceinline__ int head_of_block(const vca_loss_heads& t, int b) {
+  int e = 0;   // last head whose block_begin <= b
+  for (int i = 1; i < t.nhead; ++i)
+    if (t.h[i].block_begin <= b) e = i;
+  return e;
+}
+
+__global__ __launch_bounds__(THR) void loss_heads_fwd_kernel(const vca_loss_heads tab, float* __restrict__ out) {
+  const int e = head_of_block(tab, blockIdx.x);
+  const vca_loss_head h = tab.h[e];
+  const long long beg = (long long)(blockIdx.x - h.block_begin) * HEAD_CHUNK;
+  const long long end = beg + HEAD_CHUNK < h.n ? beg + HEAD_CHUNK : h.n;
+  const float* __restrict__ x = h.x;
+  const float* __restrict__ y = h.y;
+  float s = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += THR) {
+    const float v = x[i];
+    if (h.kind == HEAD_SOFTPLUS) s += softplus_f(h.sign * v);
+    else if (h.kind == HEAD_L1) s += fabsf(v - y[i]);
+    else if (h.kind == HEAD_SQSUM) s += v * v;
+    else s += v;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) {
+    s *= h.scale;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (h.slot[k] >= 0) atomicAdd(out + h.slot[k], s * h.weight[k]);
+  }
+}
+
+// gx_e = (sum_k gout[slot_ek] * w_ek) * scale_e * f_e'(x); heads without a gx pointer need no gradient
+__global__ __launch_bounds__(THR) void loss_heads_bwd_kernel(const vca_loss_heads tab,
+                                                             const float* __restrict__ gout) {
+  const int e = head_of_block(tab, blockIdx.x);
+  const vca_loss_head h = tab.h[e];
+  if (!h.gx) return;
+  float g = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (h.slot[k] >= 0) g += gout[h.slot[k]] * h.weight[k];
+  g *= h.scale;
+  const long long beg = (long long)(blockIdx.x - h.block_begin) * HEAD_CHUNK;
+  const long long end = beg + HEAD_CHUNK < h.n ? beg + HEAD_CHUNK : h.n;
+  const float* __restrict__ x = h.x;
+  const float* __restrict__ y = h.y;
+  float* __restrict__ gx = h.gx;
+  for (long long i = beg + threadIdx.x; i < end; i += THR) {
+    const float v = x[i];
+    float r;
+    if (h.kind == HEAD_SOFTPLUS) r = g * h.sign / (1.f + expf(-h.sign * v));
+    else if (h.kind == HEAD_L1) { const float d = v - y[i]; r = d > 0.f ? g : (d < 0.f ? -g : 0.f); }
+    else if (h.kind == HEAD_SQSUM) r = 2.f * g * v;
+    else r = g;
+    gx[i] = r;
   }
 }
 
@@ -141,12 +211,40 @@ extern "C" int vca_l1_bwd_f32(long long n, const float* a, const float* b, float
 
 extern "C" int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr,
                             float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
-                            void* stream) {
+                            const float* lr_dev, void* stream) {
   VCA_CHECK_ARG(n > 0 && (n % 4) == 0 && p && g && m && v && (step >= 1 || step_dev));
   if (step < 1) step = 1;
   const double bc1d = 1.0 - pow((double)beta1, (double)step), bc2d = 1.0 - pow((double)beta2, (double)step);
   const float bc1 = (float)bc1d;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n / 4)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, p, g, m,
-                     v, vmax, lr, beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d), step_dev);
+                     v, vmax, lr, beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d), step_dev, lr_dev);
+  return vca_launch_status();
+}
+
+extern "C" int vca_loss_head_chunk(void) { return HEAD_CHUNK; }
+
+static bool heads_ok(const vca_loss_heads* t) {
+  if (!t || t->nhead < 1 || t->nhead > VCA_MAX_LOSS_HEADS || t->total_blocks < 1) return false;
+  int next = 0;
+  for (int i = 0; i < t->nhead; ++i) {
+    const vca_loss_head& h = t->h[i];
+    if (!h.x || h.n < 1 || h.kind < 0 || h.kind > 3 || (h.kind == HEAD_L1 && !h.y) || h.block_begin != next) return false;
+    for (int k = 0; k < 3; ++k)
+      if (h.slot[k] >= VCA_MAX_LOSS_SLOTS) return false;
+    next += (int)((h.n + HEAD_CHUNK - 1) / HEAD_CHUNK);
+  }
+  return next == t->total_blocks;
+}
+
+extern "C" int vca_loss_heads_fwd_f32(const vca_loss_heads* heads, float* out, void* stream) {
+  VCA_CHECK_ARG(heads_ok(heads) && out);
+  hipLaunchKernelGGL(loss_heads_fwd_kernel, dim3(heads->total_blocks), dim3(THR), 0, (hipStream_t)stream, *heads, out);
+  return vca_launch_status();
+}
+
+extern "C" int vca_loss_heads_bwd_f32(const vca_loss_heads* heads, const float* gout, void* stream) {
+  VCA_CHECK_ARG(heads_ok(heads) && gout);
+  hipLaunchKernelGGL(loss_heads_bwd_kernel, dim3(heads->total_blocks), dim3(THR), 0, (hipStream_t)stream, *heads,
+                     gout);
   return vca_launch_status();
 }

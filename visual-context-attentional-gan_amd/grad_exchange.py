@@ -6,21 +6,27 @@ import torch.distributed as dist
 
 
 class GradExchange:
-    """Mean all-reduce of flat gradient buffers (one RCCL call per module, issued back to back and waited together)."""
+    """Mean all-reduce of flat gradient buffers.  A side of the step (the discriminators, or v_front + generator +
+    postnet) keeps its gradients in one contiguous buffer, so its exchange is a single collective: RCCL averages in
+    the reduction itself (ReduceOp.AVG); backends without it (gloo) sum and scale."""
 
-    def __init__(self, gflats, group=None):
+    def __init__(self, gflats, group=None, force=False):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
         self.gflats = list(gflats)
-        # VCA_FORCE_EXCHANGE=1 keeps the collectives (and the segmented graph replay built around them) in a
-        # single-rank job: a one-GPU rehearsal of everything the multi-GPU run does except the xGMI traffic.
-        forced = os.environ.get('VCA_FORCE_EXCHANGE') == '1' and dist.is_available() and dist.is_initialized()
+        # force (or VCA_FORCE_EXCHANGE=1) keeps the collectives, and the segmented graph replay built around them,
+        # in a single-rank job: a one-GPU rehearsal of everything the multi-GPU run does except the xGMI traffic.
+        forced = (force or os.environ.get('VCA_FORCE_EXCHANGE') == '1') and ready
         self.active = self.world > 1 or forced
+        self.avg = ready and dist.get_backend(group) == 'nccl'
 
     def reduce(self):
         if not self.active:
             return
-        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for g in self.gflats]
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(g, op=op, group=self.group, async_op=True) for g in self.gflats]
         for w, g in zip(works, self.gflats):
             w.wait()
-            g.mul_(1.0 / self.world)
+            if not self.avg:
+                g.mul_(1.0 / self.world)

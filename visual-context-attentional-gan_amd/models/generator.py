@@ -232,13 +232,19 @@ class Decoder(nn.Module):
 
     def forward(self, s, x, len, noise=None):
         """s: (B, 512, T) sentence features; x: (B, T, 512) phonemes; len: valid frames per clip.
-        noise: optional (B, 128, 20, T) tensor; by default drawn from the CPU generator like generator.py:248."""
+        noise: optional (B, 128, 20, T) tensor; by default drawn from the CPU generator like generator.py:248;
+        the string 'device' draws it on the GPU instead (ops.randn: no host draw and no host-to-device copy, fresh
+        values on every replay of a captured step; not torch's random stream)."""
         B, T = x.size(0), x.size(1)
         ctx = s.transpose(1, 2).contiguous()                             # (B, T, 512)
         len = ops.as_lens(len, x.device)
-        if noise is None:
-            noise = torch.randn([B, 128, 20, T])
-        noise = noise.to(x.device).permute(0, 2, 3, 1)                   # (B, 20, T, 128) channels-last view
+        if isinstance(noise, str):
+            assert noise == 'device', noise
+            noise = ops.randn((B, 20, T, 128), x.device)                 # channels-last already
+        else:
+            if noise is None:
+                noise = torch.randn([B, 128, 20, T])
+            noise = noise.to(x.device).permute(0, 2, 3, 1)               # (B, 20, T, 128) channels-last view
         if TILED_INPUT:
             h = self.decode[0].forward_tiled(x, noise.contiguous())      # phonemes tiled | noise, never materialised
         else:

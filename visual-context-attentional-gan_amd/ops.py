@@ -9,6 +9,7 @@ Every Function's backward is itself built from differentiable Functions (forward
 gradient and weight gradient form a closed family), which is what the R1 penalty's
 autograd.grad(create_graph=True) (train.py:188-194) needs.
 """
+import ctypes
 import weakref
 
 import torch
@@ -39,7 +40,11 @@ def step_begin(device):
     if a is None:
         a = _arena[device] = [torch.zeros(_ARENA_FLOATS, device=device, dtype=torch.float32), 0, False, 0]
     a[3] = max(a[3], a[1])
-    if a[3]:
+    if torch.cuda.is_current_stream_capturing():
+        # the fill length is frozen into the graph: it must cover whatever the captured step carves out, and that
+        # is only known once the step has run, so clear the whole arena (32 MiB, ~10 us)
+        a[0].zero_()
+    elif a[3]:
         a[0][:a[3]].zero_()
     a[1], a[2] = 0, True
 
@@ -1105,6 +1110,12 @@ _rng_calls = [0]    # dropout call sites seen since the last advance (distinct s
 _rng_seed = [0x5EED]
 
 
+def set_seed(seed, rank=0):
+    """Seed of every dropout stream of this process.  Data-parallel ranks must pass their rank (build_models /
+    GanStep do): with equal seeds every replica would draw the same masks on its own shard."""
+    _rng_seed[0] = ((int(seed) & 0xFFFFFFFF) * 0x9E3779B1 + (int(rank) + 1) * 0xC2B2AE3D) & 0xFFFFFFFFFFFFFFFF
+
+
 def rng_advance(device):
     """Move every dropout stream on: call once per training step (a device-side add, so it is captured with the
     step and replays draw fresh masks)."""
@@ -1125,7 +1136,7 @@ class DropoutFn(torch.autograd.Function):
         if step is None:
             step = _rng_step[x.device] = torch.zeros(1, device=x.device, dtype=torch.int32)
         _rng_calls[0] += 1
-        seed = (_rng_seed[0] * 0x9E3779B1 + _rng_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        seed = (_rng_seed[0] * 0x9E3779B1 + _rng_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF   # set_seed()
         check(_lib.lib().vca_dropout_f32(x.numel(), ptr(x), float(p), seed, step.data_ptr(), ptr(y), mask.data_ptr(),
                                          stream()), 'dropout')
         ctx.save_for_backward(mask)
@@ -1140,6 +1151,19 @@ class DropoutFn(torch.autograd.Function):
         check(_lib.lib().vca_dropout_bwd_f32(gy.numel(), ptr(_c(gy)), mask.data_ptr(), ctx.p, ptr(gx), stream()),
               'dropout_bwd')
         return gx, None
+
+
+def randn(shape, device):
+    """Standard-normal tensor drawn on the device by the counter-based generator (its own stream per call site and
+    training step, like the dropout masks; not torch's generator)."""
+    y = torch.empty(shape, device=device, dtype=torch.float32)
+    step = _rng_step.get(y.device)
+    if step is None:
+        step = _rng_step[y.device] = torch.zeros(1, device=y.device, dtype=torch.int32)
+    _rng_calls[0] += 1
+    seed = (_rng_seed[0] * 0x9E3779B1 + _rng_calls[0] * 0x85EBCA77 + 0x6E6F697365) & 0xFFFFFFFFFFFFFFFF
+    check(_lib.lib().vca_randn_f32(y.numel(), seed, step.data_ptr(), ptr(y), stream()), 'randn')
+    return y
 
 
 def dropout(x, p, training):
@@ -1212,6 +1236,81 @@ def l1_mean(a, b, mul=1.0):
     """mean |mul*a - mul*b| with the gradient flowing to `a` only (nn.L1Loss of an affine map of both arguments:
     the mel de-normalisation of vid_aud_grid.py:238-240 has slope `mul`)."""
     return L1MeanFn.apply(a, b.detach(), float(mul))
+
+
+HEAD_SOFTPLUS, HEAD_L1, HEAD_SQSUM, HEAD_SUM = 0, 1, 2, 3
+
+
+class LossHeadsFn(torch.autograd.Function):
+    """Every loss term of one phase of the step in one launch, forward and backward.  `heads` is a tuple of
+    (kind, x index, y index or None, sign, scale, ((slot, weight), ...)) over the tensor arguments: head e reduces
+    v = scale * sum f(x[, y]) and adds weight * v into each of its slots of the returned (nslots,) vector, so a slot
+    holds a reported term or a weighted total of several.  Gradients flow to the x tensors only."""
+
+    @staticmethod
+    def _table(heads, tensors, gxs):
+        L = _lib.lib()
+        chunk = L.vca_loss_head_chunk()
+        t = _lib.LossHeads()
+        assert len(heads) <= _lib.MAX_LOSS_HEADS
+        t.nhead = len(heads)
+        blocks = 0
+        for e, (kind, xi, yi, sign, scale, slots) in enumerate(heads):
+            h = t.h[e]
+            x = tensors[xi]
+            h.x, h.y = x.data_ptr(), (tensors[yi].data_ptr() if yi is not None else None)
+            h.gx = gxs[e].data_ptr() if (gxs is not None and gxs[e] is not None) else None
+            h.n, h.kind, h.block_begin, h.sign, h.scale = x.numel(), kind, blocks, sign, scale
+            for k in range(3):
+                h.slot[k], h.weight[k] = (slots[k][0], slots[k][1]) if k < len(slots) else (-1, 0.0)
+            blocks += (x.numel() + chunk - 1) // chunk
+        t.total_blocks = blocks
+        return t
+
+    @staticmethod
+    def forward(ctx, heads, nslots, *tensors):
+        assert nslots <= _lib.MAX_LOSS_SLOTS
+        tensors = tuple(_c(t.detach()) for t in tensors)
+        for t in tensors:
+            assert t.is_cuda and t.dtype == torch.float32
+        out = _zeros((nslots,), tensors[0].device)
+        tab = LossHeadsFn._table(heads, tensors, None)
+        check(_lib.lib().vca_loss_heads_fwd_f32(ctypes_ref(tab), ptr(out), stream()), 'loss_heads_fwd')
+        ctx.heads = heads
+        ctx.save_for_backward(*tensors)
+        return out.clone() if _arena_active(out.device) else out   # the arena slice is recycled by the next step
+
+    @staticmethod
+    @once
+    def backward(ctx, gout):
+        tensors = ctx.saved_tensors
+        heads = ctx.heads
+        gxs, grads = [], [None] * len(tensors)
+        for kind, xi, yi, sign, scale, slots in heads:
+            if ctx.needs_input_grad[2 + xi]:
+                assert grads[xi] is None, 'a tensor may feed one head only'
+                grads[xi] = torch.empty_like(tensors[xi])
+                gxs.append(grads[xi])
+            else:
+                gxs.append(None)
+        if any(g is not None for g in gxs):
+            tab = LossHeadsFn._table(heads, tensors, gxs)
+            check(_lib.lib().vca_loss_heads_bwd_f32(ctypes_ref(tab), ptr(_c(gout)), stream()), 'loss_heads_bwd')
+        return (None, None) + tuple(grads)
+
+
+def ctypes_ref(obj):
+    return ctypes.byref(obj)
+
+
+def _arena_active(device):
+    a = _arena.get(device)
+    return a is not None and a[2]
+
+
+def loss_heads(heads, nslots, tensors):
+    """See LossHeadsFn.  Returns the (nslots,) vector of weighted sums."""
+    return LossHeadsFn.apply(tuple(heads), nslots, *tensors)
 
 
 # --------------------------------------------------------------------------- #
@@ -1521,15 +1620,20 @@ class _RepackPlan:
             ent[1][m + 10] = (_wkey(p), t)
 
 
-def flatten_module(module):
+def flatten_module(module, storage=None):
     """Re-home every parameter of `module` (already on its device) into one flat fp32 buffer and give it a flat,
-    persistent gradient buffer: p.data and p.grad become views.  Returns (flat_params, flat_grads)."""
+    persistent gradient buffer: p.data and p.grad become views.  Returns (flat_params, flat_grads).  `storage`:
+    optional (params, grads) pair of zeroed buffers of module_flat_size(module) floats to use instead of new ones."""
     ps = [p for p in module.parameters()]
     sizes = [(p.numel() + 3) // 4 * 4 for p in ps]
     total = sum(sizes)
     dev = ps[0].device
-    flat = torch.zeros(total, device=dev, dtype=torch.float32)
-    gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+    if storage is None:
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+    else:
+        flat, gflat = storage
+        assert flat.numel() == total and gflat.numel() == total and flat.device == dev
     off = 0
     epoch = [0]
     for p, sz in zip(ps, sizes):
@@ -1545,16 +1649,43 @@ def flatten_module(module):
     return flat, gflat
 
 
+def module_flat_size(module):
+    return sum((p.numel() + 3) // 4 * 4 for p in module.parameters())
+
+
+def flatten_modules(modules):
+    """flatten_module for several networks that share an optimizer: their flat buffers are consecutive slices of one
+    parameter buffer and one gradient buffer, so the data-parallel exchange of the whole side is a single all-reduce.
+    Returns ([(flat_params, flat_grads) per module], all_params, all_grads)."""
+    sizes = [module_flat_size(m) for m in modules]
+    dev = next(modules[0].parameters()).device
+    allp = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    allg = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    out, off = [], 0
+    for m, sz in zip(modules, sizes):
+        out.append(flatten_module(m, (allp[off:off + sz], allg[off:off + sz])))
+        off += sz
+    return out, allp, allg
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (coupled L2 weight decay, optional amsgrad; train.py:82-83) as one kernel launch
-    per flat buffer.  `groups` is a list of (flat_params, flat_grads) from flatten_module."""
+    per flat buffer.  `groups` is a list of (flat_params, flat_grads) from flatten_module.
+
+    The step count and the learning rate live in device words read by the kernel, so a step captured into a HIP
+    graph keeps counting and keeps following `param_groups[0]['lr']` (the MultiStepLR schedules of train.py:85-86):
+    step() refreshes the device word when the host value changed, and a caller that replays a captured step calls
+    sync_lr() before each replay (GraphedStep does)."""
 
     def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
         self.groups = groups
         self.lr, self.betas, self.eps, self.weight_decay, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
         self.param_groups = [dict(lr=lr)]       # the reference reads param_groups[0]['lr'] for logging
         self.t = 0
-        self.t_dev = torch.zeros(1, device=groups[0][0].device, dtype=torch.int32)   # graph-replayable step count
+        dev = groups[0][0].device
+        self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)   # graph-replayable step count
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+        self._lr_written = float(lr)
         self.state = [dict(m=torch.zeros_like(f), v=torch.zeros_like(f),
                            vmax=torch.zeros_like(f) if amsgrad else None) for f, _ in groups]
         self.repack = [_RepackPlan(_flat_params[f.data_ptr()]) if f.data_ptr() in _flat_params else None
@@ -1564,14 +1695,24 @@ class FusedAdam:
         for _, g in self.groups:
             g.zero_()
 
+    def sync_lr(self):
+        """Copy param_groups[0]['lr'] to the device word the kernel reads, if it changed.  Never call while the
+        stream is capturing (the copy would be baked into the graph with today's value)."""
+        lr = float(self.param_groups[0]['lr'])
+        if lr != self._lr_written:
+            self.lr_dev.copy_(torch.full((1,), lr, dtype=torch.float32), non_blocking=False)
+            self._lr_written = lr
+
     def step(self):
         self.t += 1
         self.t_dev += 1
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
         lr = self.param_groups[0]['lr']
         for (f, g), st in zip(self.groups, self.state):
             check(_lib.lib().vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
-                                          self.t_dev.data_ptr(), stream()), 'adam')
+                                          self.t_dev.data_ptr(), self.lr_dev.data_ptr(), stream()), 'adam')
             ep = _flat_epoch.get(f.data_ptr())
             if ep is not None:
                 ep[0] += 1

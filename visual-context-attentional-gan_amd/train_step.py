@@ -40,12 +40,15 @@ def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
     over (dis1, dis2, dis3, s_dis).  Each module's parameters are re-homed into one flat buffer with a persistent
     flat gradient, so an optimizer step is one kernel per module and a gradient exchange is one all-reduce per
     module with no packing copies.  Call after the modules are on their device."""
-    flats = {n: ops.flatten_module(models[n]) for n in G_NAMES + D_NAMES}
-    g = ops.FusedAdam([flats[n] for n in G_NAMES], lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
-    d = ops.FusedAdam([flats[n] for n in D_NAMES], lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
-    g.flats = {n: flats[n] for n in G_NAMES}
-    d.flats = {n: flats[n] for n in D_NAMES}
-    return g, d
+    opts = []
+    for names in (G_NAMES, D_NAMES):
+        # one contiguous parameter buffer and one gradient buffer per optimizer, a slice per network
+        flats, _, allg = ops.flatten_modules([models[n] for n in names])
+        o = ops.FusedAdam(flats, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+        o.flats = dict(zip(names, flats))
+        o.all_grads = allg
+        opts.append(o)
+    return tuple(opts)
 
 
 def denormalize(m):
@@ -53,18 +56,49 @@ def denormalize(m):
     return (m + 1.0) * (-_LOG_EPS / 2.0) + _LOG_EPS
 
 
+class _Heads:
+    """Collects the loss terms of a phase for ops.loss_heads (one forward and one backward launch for all of them)."""
+
+    def __init__(self):
+        self.heads, self.tensors = [], []
+
+    def add(self, kind, x, slots, y=None, sign=1.0, scale=None):
+        xi = len(self.tensors)
+        self.tensors.append(x)
+        yi = None
+        if y is not None:
+            yi = len(self.tensors)
+            self.tensors.append(y)
+        self.heads.append((kind, xi, yi, float(sign), float(1.0 / x.numel() if scale is None else scale),
+                           tuple((int(s), float(w)) for s, w in slots)))
+
+    def run(self, nslots):
+        return ops.loss_heads(self.heads, nslots, self.tensors)
+
+
 class GanStep:
     """Callable running one full G+D step; variant 'grid' = train.py, 'lrs' = train_LRS.py."""
 
-    def __init__(self, models, optimizers, variant='grid', group=None):
+    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False):
         self.m = models
         self.g_opt, self.d_opt = optimizers
         self.variant = variant
         self.gflat = {n: gf for opt in optimizers for n, (_, gf) in opt.flats.items()}
-        self.d_exchange = GradExchange([self.gflat[n] for n in D_NAMES], group=group)
-        self.g_exchange = GradExchange([self.gflat[n] for n in G_NAMES], group=group)
+        self.d_exchange = GradExchange([self.d_opt.all_grads], group=group, force=force_exchange)
+        self.g_exchange = GradExchange([self.g_opt.all_grads], group=group, force=force_exchange)
+        self._seeds = {}
+        if dist.is_available() and dist.is_initialized():
+            ops.set_seed(torch.initial_seed(), dist.get_rank(group))   # each replica draws its own dropout masks
 
     def _zero(self, names):
+        """Clear the flat gradients of the named networks; whole sides (contiguous buffers) with one fill."""
+        names = tuple(names)
+        if names[:len(D_NAMES)] == D_NAMES:
+            self.d_opt.all_grads.zero_()
+            names = names[len(D_NAMES):]
+        if names == G_NAMES:
+            self.g_opt.all_grads.zero_()
+            names = ()
         for n in names:
             self.gflat[n].zero_()
 
@@ -99,24 +133,41 @@ class GanStep:
         # per phase) the D phase stops at the phoneme features and their gradient is added to the G phase's before
         # v_front is traversed once: v_front.grad = J^T (g_D + g_G) = J^T g_D + J^T g_G.
         phon_d = phon.detach().requires_grad_(True)
-        sync_loss = m['s_dis'](phon_d, reals[2]).mean()
-        grad_p = []
-        for (u, _), r in zip(real_lo, reals):
+        sync = m['s_dis'](phon_d, reals[2])
+        # All loss terms of the phase go through one reduction launch (and one backward launch):
+        # slot 0 dis_loss = real + fake + w * sync (train.py:200-205 / train_LRS.py:211-218), 1 sync_loss, 2-4 the R1
+        # terms mean_b ||d u_i / d real_i||^2 (train.py:188-194, weight 1/3 each in real_loss).
+        hd = _Heads()
+        B = mel.size(0)
+        for i, ((u, _), r) in enumerate(zip(real_lo, reals)):
             with ops.input_grads_only():
                 gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
-            grad_p.append(gr.reshape(gr.size(0), -1).pow(2).sum(1).mean())
+            hd.add(ops.HEAD_SQSUM, gr, ((2 + i, 1.0), (0, 1.0 / 3)), scale=1.0 / B)
         fake_lo = [d(g.detach(), sd, T) for d, g in zip(dis, (g1, g2, g3))]
-        real_loss = (sum(G.gan_loss(u, True) for u, _ in real_lo)
-                     + sum(G.gan_loss(c, True) for _, c in real_lo)) / 3 + sum(grad_p) / 3
-        fake_loss = (sum(G.gan_loss(u, False) for u, _ in fake_lo)
-                     + sum(G.gan_loss(c, False) for _, c in fake_lo)) / 3
-        dis_loss = real_loss + fake_loss + (1.0 if self.variant == 'grid' else 0.5) * sync_loss
+        for u, c in real_lo:                  # gan_loss(x, True) = mean softplus(-x), generator.py:363-366
+            hd.add(ops.HEAD_SOFTPLUS, u, ((0, 1.0 / 3),), sign=-1.0)
+            hd.add(ops.HEAD_SOFTPLUS, c, ((0, 1.0 / 3),), sign=-1.0)
+        for u, c in fake_lo:
+            hd.add(ops.HEAD_SOFTPLUS, u, ((0, 1.0 / 3),), sign=1.0)
+            hd.add(ops.HEAD_SOFTPLUS, c, ((0, 1.0 / 3),), sign=1.0)
+        hd.add(ops.HEAD_SUM, sync, ((1, 1.0), (0, 1.0 if self.variant == 'grid' else 0.5)))
+        out = hd.run(5)
         self._zero(D_NAMES)
         with ops.direct_param_grad():
-            dis_loss.backward()
+            out.backward(self._onehot(5, 0, out.device))
         self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
-                        tgt=[r.detach() for r in reals], dis_loss=dis_loss.detach(), sync_loss=sync_loss.detach(),
-                        grad_p=torch.stack([x.detach() for x in grad_p]))
+                        tgt=[r.detach() for r in reals], dis_loss=out[0].detach(), sync_loss=out[1].detach(),
+                        grad_p=out[2:5].detach())
+
+    def _onehot(self, n, i, device):
+        """Constant seed gradient selecting slot i of a loss vector (built once, so a captured step holds no fill)."""
+        key = (n, i, device)
+        t = self._seeds.get(key)
+        if t is None:
+            t = torch.zeros(n, device=device, dtype=torch.float32)
+            t[i] = 1.0
+            self._seeds[key] = t
+        return t
 
     def g_phase(self):
         """d_optimizer.step(), then the generator losses and their backward (train.py:211-235)."""
@@ -132,25 +183,29 @@ class GanStep:
             p.requires_grad_(False)
         gs = m['post'](g3)
         gen_lo = [d(g, sd, T) for d, g in zip(dis, (g1, g2, g3))]
-        g_sync = m['s_dis'](phon.detach(), g3, gen=True).mean()
-        g_adv = (sum(G.gan_loss(u, True) for u, _ in gen_lo) + sum(G.gan_loss(c, True) for _, c in gen_lo)) / 3
-        tgt = st['tgt']
-        if self.variant == 'grid':
-            g_loss = g_adv + g_sync
-            k = -_LOG_EPS / 2.0           # slope of the de-normalisation applied to both L1 arguments
-            recon = sum(ops.l1_mean(g, t, k) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, st['spec'])
-            gen_loss = g_loss + 50.0 * recon
-        else:
-            g_loss = g_adv
-            recon = sum(ops.l1_mean(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + ops.l1_mean(gs, st['spec'])
-            gen_loss = g_loss + 50.0 * recon + g_sync
+        g_sync = m['s_dis'](phon.detach(), g3, gen=True)
+        # slot 0 gen_loss, 1 g_loss, 2 recon_loss, 3 g_sync_loss.  GRID (train.py:222-231): g_loss = adv/3 + g_sync,
+        # recon = L1(denorm g_i, denorm mel_i)/3 + L1(gs, spec), gen = g_loss + 50 recon; LRS (train_LRS.py:226-237):
+        # g_loss = adv/3, recon on the normalised mels, gen = g_loss + 50 recon + g_sync.
+        hd = _Heads()
+        for u, c in gen_lo:
+            hd.add(ops.HEAD_SOFTPLUS, u, ((1, 1.0 / 3), (0, 1.0 / 3)), sign=-1.0)
+            hd.add(ops.HEAD_SOFTPLUS, c, ((1, 1.0 / 3), (0, 1.0 / 3)), sign=-1.0)
+        grid = self.variant == 'grid'
+        hd.add(ops.HEAD_SUM, g_sync, ((3, 1.0), (1, 1.0), (0, 1.0)) if grid else ((3, 1.0), (0, 1.0)))
+        k = (-_LOG_EPS / 2.0) if grid else 1.0      # slope of the de-normalisation applied to both L1 arguments
+        for g, t in zip((g1, g2, g3), st['tgt']):
+            hd.add(ops.HEAD_L1, g, ((2, 1.0 / 3), (0, 50.0 / 3)), y=t, scale=k / g.numel())
+        hd.add(ops.HEAD_L1, gs, ((2, 1.0), (0, 50.0)), y=st['spec'])
+        out = hd.run(4)
         self._zero(D_NAMES + ('gen', 'post'))
         with ops.direct_param_grad():
-            torch.autograd.backward([gen_loss, phon], [None, st['phon_d'].grad])
+            torch.autograd.backward([out, phon], [self._onehot(4, 0, out.device), st['phon_d'].grad])
         for p in d_params:
             p.requires_grad_(True)
-        self._st = dict(dis_loss=st['dis_loss'], gen_loss=gen_loss.detach(), sync_loss=st['sync_loss'],
-                        g_sync_loss=g_sync.detach(), recon_loss=recon.detach(), g_loss=g_loss.detach(),
+        out = out.detach()
+        self._st = dict(dis_loss=st['dis_loss'], gen_loss=out[0], sync_loss=st['sync_loss'],
+                        g_sync_loss=out[3], recon_loss=out[2], g_loss=out[1],
                         grad_p=st['grad_p'], g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
 
     def finish(self):
@@ -167,13 +222,21 @@ class GraphedStep:
     segmented=True) the three phases are three graphs sharing one memory pool, replayed in order with the two
     gradient all-reduces issued between them on the same stream, so no collective is ever captured.  Inputs are
     copied into static device buffers before each replay; the returned tensors are the graphs' static outputs
-    (overwritten by the next call).  Shapes are fixed at capture."""
+    (overwritten by the next call).  Shapes are fixed at capture.
 
-    def __init__(self, step, mel, spec, vid, vid_len, noise, warmup=2, segmented=None):
+    Decoder noise (generator.py:248 draws it afresh every step): with noise='device' (the default) the captured step
+    draws it on the GPU from the counter-based generator, so every replay sees new noise; with a tensor the caller
+    supplies the noise of every call (passing None on a later call is an error, never a silent reuse)."""
+
+    def __init__(self, step, mel, spec, vid, vid_len, noise='device', warmup=2, segmented=None):
+        assert warmup >= 1, 'one uncaptured step must run first: lazy state and the scratch arena settle there'
         self.step = step
         dev = mel.device
-        self.static = dict(mel=mel.clone(), spec=spec.clone(), vid=vid.clone(), noise=noise.clone(),
+        self.device_noise = isinstance(noise, str)
+        self.static = dict(mel=mel.clone(), spec=spec.clone(), vid=vid.clone(),
                            vid_len=torch.as_tensor([int(l) for l in vid_len], device=dev))
+        if not self.device_noise:
+            self.static['noise'] = noise.clone()
         self.segmented = step.d_exchange.active if segmented is None else bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -183,6 +246,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         s = self.static
+        nz = 'device' if self.device_noise else s['noise']
         if not self.segmented:
             self.graphs = [torch.cuda.CUDAGraph()]
             with torch.cuda.graph(self.graphs[0]):
@@ -193,7 +257,7 @@ class GraphedStep:
             pool = torch.cuda.graph_pool_handle()
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
-                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], s['noise'])
+                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz)
             step.d_exchange.reduce()         # keeps the ranks' collective sequences aligned; the data is not used
             with torch.cuda.graph(self.graphs[1], pool=pool, capture_error_mode=mode):
                 step.g_phase()
@@ -204,15 +268,22 @@ class GraphedStep:
 
     def _run(self):
         s = self.static
-        return self.step(s['mel'], s['spec'], s['vid'], s['vid_len'], noise=s['noise'])
+        return self.step(s['mel'], s['spec'], s['vid'], s['vid_len'],
+                         noise='device' if self.device_noise else s['noise'])
 
     def __call__(self, mel, spec, vid, vid_len=None, noise=None):
         s = self.static
+        if self.device_noise:
+            assert noise is None or isinstance(noise, str), 'this step was captured with on-device noise'
+        else:
+            assert torch.is_tensor(noise), 'this step was captured with caller-supplied noise: pass the tensor'
         for k, v in (('mel', mel), ('spec', spec), ('vid', vid), ('noise', noise)):
-            if v is not None and v.data_ptr() != s[k].data_ptr():
+            if torch.is_tensor(v) and v.data_ptr() != s[k].data_ptr():
                 s[k].copy_(v, non_blocking=True)
         if vid_len is not None and not (torch.is_tensor(vid_len) and vid_len.data_ptr() == s['vid_len'].data_ptr()):
             s['vid_len'].copy_(torch.as_tensor([int(l) for l in vid_len]), non_blocking=True)
+        self.step.g_opt.sync_lr()            # the captured Adam launches read the learning rate from device words
+        self.step.d_opt.sync_lr()
         if not self.segmented:
             self.graphs[0].replay()
         else:
