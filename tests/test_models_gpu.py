@@ -119,8 +119,15 @@ def test_step_matches_reference(variant, prec):
             check_step(m, res, g, s, loss_rtol=5e-5, out_atol=2e-4, grad_rel=5e-2, param_p90=2e-5, skip_grads=D)
         elif s == 0:
             check_step(m, res, g, s, loss_rtol=5e-4, out_atol=3e-3, grad_rel=0.15, param_p90=2.1e-4, skip_grads=D)
+        elif prec == 'fp32':
+            # Second step: the first Adam update moves every weight by ~lr * sign(grad), so last-bit differences in
+            # step 0's gradients flip signs of small entries and the two runs part (the CPU oracle run twice with a
+            # 1e-6 input perturbation parts as far).  Measured here (tools/step_tolerance.py): loss 1.1e-4 / 7.0e-4,
+            # outputs 3.9e-2, mel-L1 4.5e-3, gradients 0.17 / 0.20 (GRID / LRS); bounds = about twice that.
+            check_step(m, res, g, s, loss_rtol=1.5e-3, out_atol=8e-2, grad_rel=0.4, param_p90=2.1e-4, skip_grads=D)
         else:
-            check_step(m, res, g, s, loss_rtol=3e-3, out_atol=0.25, grad_rel=0.7, param_p90=2.1e-4, skip_grads=D)
+            # bf16x3 / mixed measured: loss 3.0e-4 / 1.7e-3, outputs 6.4e-2, mel-L1 8.6e-3, gradients 0.19 / 0.26
+            check_step(m, res, g, s, loss_rtol=3e-3, out_atol=0.13, grad_rel=0.5, param_p90=2.1e-4, skip_grads=D)
 
 
 @gpu

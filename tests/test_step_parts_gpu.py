@@ -120,7 +120,7 @@ def test_graphed_step_noise_contract():
     gs = train_step.GraphedStep(step, b['mel'], b['spec'], b['vid'], b['vid_len'], 'device', warmup=1)
     a = gs(b['mel'], b['spec'], b['vid'])['g3'].clone()
     c = gs(b['mel'], b['spec'], b['vid'])['g3'].clone()
-    assert float((a - c).abs().max()) > 1e-4                       # same weights and inputs, different noise
+    assert float((a - c).abs().max()) > 1e-2                       # same weights and inputs, different noise
     with pytest.raises(AssertionError):
         gs(b['mel'], b['spec'], b['vid'], None, b['noise'])
     gt = train_step.GraphedStep(step, b['mel'], b['spec'], b['vid'], b['vid_len'], b['noise'], warmup=1)
@@ -128,7 +128,7 @@ def test_graphed_step_noise_contract():
         gt(b['mel'], b['spec'], b['vid'])
     a = gt(b['mel'], b['spec'], b['vid'], None, b['noise'])['g3'].clone()
     c = gt(b['mel'], b['spec'], b['vid'], None, b['noise'])['g3'].clone()
-    assert float((a - c).abs().max()) < 1e-4
+    assert float((a - c).abs().max()) < 3e-3                       # same noise: equal up to atomic-add order
 
 
 @gpu
