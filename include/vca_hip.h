@@ -305,6 +305,18 @@ int vca_hband_reduce_f32(int B, int H, int W, int C, int K, int pad, const float
  * biases).  partial is scratch of vca_colsum_groups(P, C) * C floats (need not be initialised). */
 int vca_colsum_groups(int P, int C);
 int vca_colsum_add_f32(int P, int C, const float* x, float* partial, float* dst, void* stream);
+/* vca_colsum_add_f32 for callers that cannot allocate device memory or bring a workspace (code under HIP graph
+ * capture, serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The partial sums live
+ * in a fixed 4 MiB device array inside the library (one copy per GPU, held until the process ends), so the call
+ * allocates nothing; sizes with vca_colsum_groups(P, C) * C > vca_colsum_noalloc_max_floats() are refused with
+ * VCA_E_SCRATCH_LIMIT.  All calls on one GPU share that array: calls that overlap on one GPU (different streams
+ * without ordering) race; calls on one stream are safe back to back.  vca_noalloc_init() resolves the array's address
+ * for the CURRENT device; call it once per device at set-up (the entry point does it on its first call on a device
+ * otherwise, which must then not happen under stream capture). */
+#define VCA_E_SCRATCH_LIMIT (-27)
+int vca_noalloc_init(void);
+long long vca_colsum_noalloc_max_floats(void);
+int vca_colsum_add_noalloc_f32(int P, int C, const float* x, float* dst, void* stream);
 /* y[n][c] = mean of x[n][0:wh][0:ww][c] (nn.AvgPool2d(4) with a 1x1 output, resnet.py:82; .mean([2,3]) of the
  * discriminator heads, generator.py:310,316) and its adjoint. */
 int vca_window_mean_f32(int N, int H, int W, int C, int wh, int ww, const float* x, float* y, void* stream);

@@ -98,6 +98,9 @@ _SIGS = {
     'vca_concat2_bwd_f32': ([_I, _I, _I, _I, _I, _I, _P, _LL, _LL, _LL, _I, _P, _P], _I),
     'vca_colsum_groups': ([_I, _I], _I),
     'vca_colsum_add_f32': ([_I, _I, _P, _P, _P, _P], _I),
+    'vca_noalloc_init': ([], _I),
+    'vca_colsum_noalloc_max_floats': ([], _LL),
+    'vca_colsum_add_noalloc_f32': ([_I, _I, _P, _P, _P], _I),
     'vca_hband_expand_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P], _I),
     'vca_hband_reduce_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'vca_window_mean_f32': ([_I, _I, _I, _I, _I, _I, _P, _P, _P], _I),

@@ -1,6 +1,8 @@
 // Data-movement kernels of the step on channels-last maps: channel concatenation with broadcast (the decoder's
 // [phonemes tiled over frequency | noise] input, the attention merges, the discriminators' conditioning vector),
 // window means (AvgPool2d(4) head, spatial means of the discriminator heads), dropout, and the mel pyramid.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -267,6 +269,60 @@ extern "C" int vca_colsum_groups(int P, int C) {
 extern "C" int vca_colsum_add_f32(int P, int C, const float* x, float* partial, float* dst, void* stream) {
   VCA_CHECK_ARG(P > 0 && C > 0 && x && partial && dst);
   const int g = vca_colsum_groups(P, C);
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
+  hipLaunchKernelGGL(colsum_fold_add_kernel, dim3((C + 31) / 32), dim3(THR), 0, (hipStream_t)stream, g, C, partial,
+                     dst);
+  return vca_launch_status();
+}
+
+// ---- the same column sum for callers that cannot allocate: the partial sums live in a fixed device array of the
+// library instead of a caller-supplied workspace.  Every GPU holds its own copy of the array at its own address,
+// resolved once per device (with that device current) and used through that pointer only.
+namespace {
+constexpr int NOALLOC_GROUPS = 256;                        // vca_colsum_groups never returns more
+constexpr int NOALLOC_MAX_C = 4096;
+constexpr int NOALLOC_MAX_DEV = 64;
+static __device__ __align__(256) float colsum_scratch[NOALLOC_GROUPS * NOALLOC_MAX_C];   // 4 MiB per GPU
+float* scratch_ptr[NOALLOC_MAX_DEV] = {nullptr};
+std::mutex scratch_mutex;
+
+int scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= NOALLOC_MAX_DEV) return -22;
+  std::lock_guard<std::mutex> lock(scratch_mutex);
+  if (!scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(colsum_scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return -14;
+    scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int vca_noalloc_init(void) {
+  float* p = nullptr;
+  return scratch_for_current_device(&p);
+}
+
+extern "C" long long vca_colsum_noalloc_max_floats(void) { return (long long)NOALLOC_GROUPS * NOALLOC_MAX_C; }
+
+extern "C" int vca_colsum_add_noalloc_f32(int P, int C, const float* x, float* dst, void* stream) {
+  VCA_CHECK_ARG(P > 0 && C > 0 && x && dst);
+  const int g = vca_colsum_groups(P, C);
+  if (g > NOALLOC_GROUPS || (long long)g * C > (long long)NOALLOC_GROUPS * NOALLOC_MAX_C) return VCA_E_SCRATCH_LIMIT;
+  float* partial = nullptr;
+  const int rc = scratch_for_current_device(&partial);
+  if (rc != 0) return rc;
+  // colsum_partial_kernel writes every (group, column) entry the fold kernel reads, so whatever the previous call
+  // left in the array needs no clearing.
   if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, partial);
   else
