@@ -24,6 +24,12 @@ B, T, H = 32, 75, 96
 FLOP_PER_FRAME = 9.84e9          # full step at 96x96, counted on the reference with torch's FlopCounterMode
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'mixed': 2500.0}
 MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'mixed': 3}
+DTYPE_NOTE = {
+    'mixed': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every forward product and '
+             'the R1 double-backward chain, single bf16 products in the input/weight gradients; everything else fp32',
+    'bf16x3': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every product; '
+              'everything else fp32',
+}
 
 
 def synth(b, t, h, device, seed):
@@ -36,41 +42,82 @@ def synth(b, t, h, device, seed):
                 vid_len=[t] * b)
 
 
+def _time(fn, reps=5, warm=2):
+    """Average duration (seconds) of fn() from HIP events on the current stream (the one the kernels launch on)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
 def roofline_probe(device, dtype):
-    """Time the dominant kernel (the implicit-GEMM convolution) on the largest layer the step runs, decode.0.conv2
-    (5x5, 512->512 on the 20x75 map of 32 clips; decode.0.conv1 no longer sees the tiled 640-channel input), with
-    HIP events on the stream it is launched on."""
+    """Time the dominant kernel (the implicit-GEMM convolution, forward = split product in both 'bf16x3' and 'mixed')
+    on the largest layer the step runs, decode.0.conv2 (5x5, 512->512 on the 20x75 map of 32 clips; decode.0.conv1
+    no longer sees the tiled 640-channel input), with HIP events on the stream it is launched on."""
     from vcagan_amd import ops
     x = torch.randn(B, 20, T, 512, device=device)
     w = torch.nn.Parameter(torch.randn(512, 512, 5, 5, device=device) * 0.01)
     bias = torch.zeros(512, device=device)
     flops = 2.0 * B * 20 * T * 512 * 25 * 512
     with torch.no_grad():
-        for _ in range(2):
-            ops.conv2d(x, w, bias, 1, 2)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            ops.conv2d(x, w, bias, 1, 2)
-        e1.record()
-        torch.cuda.synchronize()
-    dt = e0.elapsed_time(e1) / reps * 1e-3
+        dt = _time(lambda: ops.conv2d(x, w, bias, 1, 2))
     peak = PEAK_TFLOPS[dtype]
     ach = flops / dt / 1e12                         # algorithmic (fp32-equivalent) rate
     issued = ach * MFMA_PER_PRODUCT[dtype]          # matrix-core work actually issued (3 bf16 MFMAs per product)
-    kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else 'conv_bf16_halo_kernel<128,2,2,%d>' % MFMA_PER_PRODUCT[dtype]
-    # HBM-side bytes per launch of this kernel on this layer from separate rocprofv3 --pmc passes
-    # (profiles/r1_decode0conv2_pmc.txt): 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE, in KiB.
-    # Algorithmic bytes (input + packed weights + output, each once) are 98 + 26 + 98 = 222 MB; the excess is the
-    # input halo re-read once per 128-channel output block and the weight stream re-read per pixel block, which the
-    # 256 MiB Infinity Cache absorbs (the counters sit on the L2's fabric side and include its hits).
+    kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else \
+        'conv_bf16_halo_kernel<128,2,2,%d,1>' % MFMA_PER_PRODUCT[dtype]
+    # `traffic` is NOT measured by this run: it is the fabric-side byte count of one launch of this kernel on this
+    # layer from separate rocprofv3 --pmc passes, 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE;
+    # `traffic_source` names the committed profile.  Algorithmic bytes (input + packed weights + output, each once)
+    # are 98 + 26 + 98 = 222 MB; the excess is the input halo re-read once per 128-channel output block and the
+    # weight stream re-read per pixel block, absorbed by the 256 MiB Infinity Cache.
     traffic = (2 * 525027 + 96000) * 1024 if dtype in ('bf16x3', 'mixed') else None
     return dict(bound='mfma', kernel=kern + ' on decode.0.conv2', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
-                issued_frac=round(issued / peak, 4), traffic=traffic, launch_ms=round(dt * 1e3, 3),
-                flops_per_launch=flops)
+                issued_frac=round(issued / peak, 4), traffic=traffic,
+                traffic_source='profiles/r1_decode0conv2_pmc.txt (separate --pmc passes, not this run)'
+                if traffic else None, launch_ms=round(dt * 1e3, 3), flops_per_launch=flops)
+
+
+def north_star_probes(device, models):
+    """The two stages BASELINE.json's north_star sets targets for, timed live with HIP events:
+    the 3-D convolution front-end against the HBM roofline, and the Visual Context Attention module (its four
+    projections + QK^T + mask + softmax + AV, generator.py:142-171) against the matrix-core peak."""
+    from vcagan_amd import ops
+    out = {}
+    vf = models['v_front']
+    vid = torch.randn(B, 1, T, H, H, device=device)
+    with torch.no_grad():
+        xs = vid.permute(0, 2, 3, 4, 1).contiguous()                # (B, T, H, W, 1) channels-last
+        dt = _time(lambda: vf.front(xs))
+    oh = H // 4
+    # algorithmic bytes of a1 + a2 as one stage: the clip once, the pooled map it hands to the ResNet trunk and one
+    # argmax byte per pooled element for the backward pass (the full-resolution stem output is an implementation
+    # detail: whatever of it an implementation writes and re-reads shows up as time, not as algorithmic bytes)
+    alg = B * T * H * H * 4 + B * T * oh * oh * 64 * 5
+    out['frontend'] = dict(stage='Conv3d stem + BN3d + PReLU + MaxPool3d (visual_front.py:11-14), train mode',
+                           ms=round(dt * 1e3, 3), algorithmic_bytes=alg, achieved_GBps=round(alg / dt / 1e9, 1),
+                           peak_GBps=8000.0, frac=round(alg / dt / 8e12, 4))
+    att = models['gen'].att1
+    ctx = torch.randn(B, T, 512, device=device)
+    g1 = torch.randn(B, 20, T, 128, device=device)
+    lens = torch.full((B,), T, device=device, dtype=torch.int32)
+    with torch.no_grad():
+        dt = _time(lambda: att(ctx, g1, lens))
+    S, Tq, D = T, T, 256
+    fl = 2.0 * B * (2 * S * 512 * D + Tq * 2560 * D + 2 * Tq * S * D + Tq * D * 1280)
+    peak = PEAK_TFLOPS[ops.get_precision()]
+    out['vca_module'] = dict(stage='att1: k/v/q/out projections + QK^T + mask + softmax + AV', ms=round(dt * 1e3, 3),
+                             gflop=round(fl / 1e9, 2), achieved_TFLOPs=round(fl / dt / 1e12, 1), peak_TFLOPs=peak,
+                             frac=round(fl / dt / 1e12 / peak, 4),
+                             qk_av_share_of_flops=round(2.0 * B * 2 * Tq * S * D / fl, 3))
+    return out
 
 
 def cpu_baseline():
@@ -104,7 +151,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra mixed-precision measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
-    ap.add_argument('--precision', default='bf16x3', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
+    ap.add_argument('--precision', default='mixed', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
     args = ap.parse_args()
 
     if os.environ.get('VCA_BENCH_HANG_TRACE'):      # debugging aid: dump every thread's stack if the run stalls
@@ -220,10 +267,13 @@ def main():
             'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
         }
         res['roofline'] = roofline_probe(device, dtype)
-        if world == 1 and args.precision == 'bf16x3' and graphed is not None and not args.no_alt:
-            # the same step with single-bf16 products in the plain input/weight gradients (forward and the R1 chain
-            # stay split-bf16, so outputs keep fp32-level parity); reported beside `value`, never as `value`
-            ops.set_precision('mixed')
+        res['dtype_note'] = DTYPE_NOTE.get(dtype, dtype)
+        if world == 1:
+            res['north_star'] = north_star_probes(device, models)
+        if world == 1 and graphed is not None and not args.no_alt and args.precision in ('mixed', 'bf16x3'):
+            # the same step at the other precision, reported beside `value`, never as `value`
+            alt = 'bf16x3' if args.precision == 'mixed' else 'mixed'
+            ops.set_precision(alt)
             g2 = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'], 'device')
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -232,7 +282,7 @@ def main():
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t1) / args.steps * 1e3
             ops.set_precision(args.precision)
-            res['alt_precision'] = {'dtype': 'bf16x3 forward + bf16 gradients', 'ms_per_step': round(ms2, 2),
+            res['alt_precision'] = {'dtype': alt, 'dtype_note': DTYPE_NOTE[alt], 'ms_per_step': round(ms2, 2),
                                     'value': round(frames / (ms2 * 1e-3), 1)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()

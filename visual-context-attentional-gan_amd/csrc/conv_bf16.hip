@@ -67,12 +67,24 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = *reinterpret_cast<uint4*>(&l);
 }
 
-template <int BN, int WM, int WN, int NSPLIT>
+// TPS = filter taps per pipeline stage (one barrier per stage); every launch uses 1.  Measured and rejected for the
+// single product (NSPLIT = 1, 8 MFMAs per wave and tap at BN = 128): 3 / 6 / 12 taps per stage, a ring of three
+// weight buffers requested two stages ahead, 256 output channels per workgroup, and fetching the next slice's halo a
+// stage ahead into registers - none moved the 128-channel launches by more than 3 % and the narrow ones lost up to
+// 40 % through LDS residency.  With the halo loads removed altogether the launch is only 17-19 % shorter.
+//
+// Inside a stage the (tap, 16-channel half) steps are software-pipelined by hand: the LDS fragments of step s+1 are
+// requested before the MFMAs of step s are issued (two register sets), so a wave's matrix pipe does not idle for an
+// LDS round trip after every 4..12 MFMAs.  (Fetching the next slice's halo into registers a stage ahead was measured
+// too: no gain, 48 more live registers; the loads of a slice are issued before the barrier that frees the LDS image
+// and converted behind it.)
+template <int BN, int WM, int WN, int NSPLIT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   constexpr int BROW = (NSPLIT == 3) ? 128 : 64;  // bytes of one packed weight row that are used
-  constexpr int BBUF = BN * BROW;                 // bytes of one weight LDS buffer
+  constexpr int BTAP = BN * BROW;                 // bytes of one tap's weight tile
+  constexpr int BBUF = TPS * BTAP;                // bytes of one weight LDS buffer (a stage)
 
   const vca_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,6 +109,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     const int ty = rem / a.TW, tx = rem - ty * a.TW;
     hb[i] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
   }
+  // byte offset of this lane's weight-fragment rows inside a tap's tile (first 16-channel half; the second is ^ 32)
+  int boff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 32 + lr;
+    boff[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -110,26 +129,30 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   // One wave-instruction fills 1 KiB = 16 rows x 64 B of the hi or lo image in lane order, so the XOR swizzle of
   // the image is applied to the per-lane SOURCE address: lane l -> row 16*piece + l/4, slot l%4 holds source
   // chunk (l%4) ^ ((row>>2)&3).
-  constexpr int NPIECE = BN * BROW / 1024;            // 16 (BN=128, split) ... 2 (BN=32, single)
-  constexpr int PPW = (NPIECE + 3) / 4;               // pieces per wave
+  constexpr int NPIECE = BN * BROW / 1024;            // per tap: 16 (BN=128, split) ... 2 (BN=32, single)
+  constexpr int SPIECE = NPIECE * TPS;                // per stage
+  constexpr int PPW = (SPIECE + 3) / 4;               // pieces per wave
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto issue_b = [&](int tap, int chunk, int buf) {
-    const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad) * 128;
+  const int nstage = (a.ntaps + TPS - 1) / TPS;
+  auto issue_b = [&](int stage, int chunk, int buf) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int pi = wave_u * PPW + i;
-      if (pi < NPIECE) {
+      const int si = wave_u * PPW + i;
+      const int tt = si / NPIECE, pi = si - tt * NPIECE;
+      const int tap = stage * TPS + tt;
+      if (si < SPIECE && tap < a.ntaps) {
+        const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad) * 128;
         const int part = pi / (BN / 16), pr = pi - part * (BN / 16);
         const int row = pr * 16 + (lane >> 2), slot = lane & 3;
         const int grow = min(n0 + row, a.npad - 1);    // rows past the packed matrix feed columns that are never stored
         const unsigned char* g = src + (size_t)grow * 128 + part * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-        unsigned char* l = bbase + buf * BBUF + part * (BN * 64) + pr * 1024;
+        unsigned char* l = bbase + buf * BBUF + tt * BTAP + part * (BN * 64) + pr * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
     }
   };
-  // the tile requested at the start of a tap must have landed before the barrier that ends the tap
+  // the tiles requested at the start of a stage must have landed before the barrier that ends the stage
   auto wait_b = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   // Halo staging plan of this thread, the same for every channel slice: up to 3 (position, 16-channel half) items
   // with the element offset of the source pixel (-1: padding / outside the image / dilation hole).
@@ -159,44 +182,51 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     }
   }
 
-  const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
-  const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
-  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
-    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
-    // ---- stage the halo of this 32-channel slice
+  // ---- halo of one 32-channel slice: global memory -> registers (fetch), registers -> hi/lo bf16 in LDS (store)
+  float4 pre[NHI][4];
+  auto fetch_halo = [&](int chunk) {
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      const int it = tid + k * 256;
+      const int ci0 = chunk * 32 + (it & 1) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < npos_total * 2 && hsrc[k] >= 0 && ci0 < d.Cin) {
+        const float* src = a.x + hsrc[k] + ci0;
+        if (a.vecA && ci0 + 16 <= d.Cin) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pre[k][q] = *reinterpret_cast<const float4*>(src + 4 * q);
+        } else {
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = (ci0 + j < d.Cin) ? src[j] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pre[k][q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+      }
+    }
+  };
+  auto store_halo = [&](int chunk) {
 #pragma unroll
     for (int k = 0; k < NHI; ++k) {
       const int it = tid + k * 256;
       if (it >= npos_total * 2) break;
       const int pos = it >> 1, half = it & 1;
-      const bool ok = hsrc[k] >= 0;
-      const int ci0 = chunk * 32 + half * 16;
       float v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = 0.f;
-      if (ok && ci0 < d.Cin) {
-        const float* src = a.x + hsrc[k] + ci0;
-        if (a.vecA && ci0 + 16 <= d.Cin) {
+      for (int q = 0; q < 4; ++q) {
+        v[4 * q] = pre[k][q].x; v[4 * q + 1] = pre[k][q].y; v[4 * q + 2] = pre[k][q].z; v[4 * q + 3] = pre[k][q].w;
+      }
+      if ((a.in_scale || d.act) && hsrc[k] >= 0) {   // BN-affine / activation prologue; padding stays zero
+        const int ci0 = chunk * 32 + half * 16;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (ci0 + j < d.Cin) v[j] = src[j];
-        }
-        if (a.in_scale || d.act) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int ci = ci0 + j;
-            if (ci < d.Cin) {
-              float z = v[j];
-              if (a.in_scale) z = z * a.in_scale[ci] + a.in_shift[ci];
-              if (d.act) z = vca_act(z, d.act, d.act == VCA_ACT_PRELU ? a.in_alpha[ci] : d.slope);
-              v[j] = z;
-            }
+        for (int j = 0; j < 16; ++j) {
+          const int ci = ci0 + j;
+          if (ci < d.Cin) {
+            float z = v[j];
+            if (a.in_scale) z = z * a.in_scale[ci] + a.in_shift[ci];
+            if (d.act) z = vca_act(z, d.act, d.act == VCA_ACT_PRELU ? a.in_alpha[ci] : d.slope);
+            v[j] = z;
           }
         }
       }
@@ -213,48 +243,90 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
         *reinterpret_cast<uint4*>(pl + (((2 * half + 1) ^ sw) << 4)) = l1;
       }
     }
+  };
+
+  // ---- fragments of one (tap, 16-channel half) step and their products
+  struct Frag {
+    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+  };
+  auto load_frags = [&](Frag& f, int tapoff, const unsigned char* btile, int ks) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int pa = hb[i] + tapoff;
+      const int off = (pa * 64 + ((lh ^ ((pa >> 2) & 3)) << 4)) ^ (ks << 5);
+      f.ah[i] = *reinterpret_cast<const bf16x8*>(halo_hi + off);
+      if (NSPLIT == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(halo_lo + off);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int off = boff[j] ^ (ks << 5);
+      f.bh[j] = *reinterpret_cast<const bf16x8*>(btile + off);
+      if (NSPLIT == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(btile + BN * 64 + off);
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (NSPLIT == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
+  const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
+  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+    fetch_halo(chunk);
+    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
+    store_halo(chunk);
     issue_b(0, chunk, 0);
     wait_b();
     __syncthreads();
 
-    for (int tap = 0; tap < a.ntaps; ++tap) {
-      const int buf = tap & 1;
-      if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk, buf ^ 1);
-      const int kh = tap / d.KW, kw = tap - kh * d.KW;
-      const int tapoff = kh * a.HW + kw;
-      const unsigned char* bh_base = bbase + buf * BBUF;
+    int kh = 0, kw = 0;   // filter tap the next stage starts at
+    auto compute_stage = [&](int stage) {
+      const unsigned char* bst = bbase + (stage & 1) * BBUF;
+      int toff[TPS];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = 2 * ks + lh;
-        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int pa = hb[i] + tapoff;
-          const int off = pa * 64 + ((c ^ ((pa >> 2) & 3)) << 4);
-          ah[i] = *reinterpret_cast<const bf16x8*>(halo_hi + off);
-          if (NSPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(halo_lo + off);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int row = wn * WTN + j * 32 + lr;
-          const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-          bh[j] = *reinterpret_cast<const bf16x8*>(bh_base + off);
-          if (NSPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bh_base + BN * 64 + off);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            if (NSPLIT == 3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+      for (int tt = 0; tt < TPS; ++tt) {
+        toff[tt] = kh * a.HW + kw;
+        if (++kw == d.KW) { kw = 0; ++kh; }
       }
+      const int ntap_here = min(TPS, a.ntaps - stage * TPS);
+      if (TPS == 1 || ntap_here == TPS) {
+        Frag f[2];
+        load_frags(f[0], toff[0], bst, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2 * TPS; ++s2) {
+          if (s2 + 1 < 2 * TPS) load_frags(f[(s2 + 1) & 1], toff[(s2 + 1) >> 1], bst + ((s2 + 1) >> 1) * BTAP, (s2 + 1) & 1);
+          mma(f[s2 & 1]);
+        }
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+          if (tt < ntap_here) {
+            Frag f[2];
+            load_frags(f[0], toff[tt], bst + tt * BTAP, 0);
+            load_frags(f[1], toff[tt], bst + tt * BTAP, 1);
+            mma(f[0]);
+            mma(f[1]);
+          }
+        }
+      }
+    };
+    for (int stage = 0; stage + 1 < nstage; ++stage) {
+      issue_b(stage + 1, chunk, (stage & 1) ^ 1);
+      compute_stage(stage);
       wait_b();
       __syncthreads();
     }
+    compute_stage(nstage - 1);
+    wait_b();
+    __syncthreads();
   }
 
   // ---- epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -944,9 +1016,10 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Co
   return best;
 }
 
-template <int BN, int WM, int WN, int NSPLIT>
-int launch_halo(HArgs a, int gx, int gy, size_t lds, hipStream_t s) {
-  auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
+template <int BN, int WM, int WN, int NSPLIT, int TPS>
+int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
+  auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT, TPS>;
+  const size_t lds = halo + 2 * (size_t)TPS * BN * (NSPLIT == 3 ? 128 : 64);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1124,10 +1197,9 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   const size_t halo = (size_t)a.NI * a.NPOS * 64 * (nsplit == 3 ? 2 : 1);
 #define LAUNCH_H(BN_, WM_, WN_)                                                                   \
   do {                                                                                             \
-    const size_t lds = halo + 2 * (size_t)BN_ * (nsplit == 3 ? 128 : 64);                          \
     const int gy = (d->Cout + BN_ - 1) / BN_;                                                      \
-    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3>(a, gx, gy, lds, s)                          \
-                       : launch_halo<BN_, WM_, WN_, 1>(a, gx, gy, lds, s);                         \
+    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3, 1>(a, gx, gy, halo, s)                      \
+                       : launch_halo<BN_, WM_, WN_, 1, 1>(a, gx, gy, halo, s);                     \
   } while (0)
   if (d->Cout > 64) LAUNCH_H(128, 2, 2);
   else if (d->Cout > 32) LAUNCH_H(64, 2, 2);

@@ -19,13 +19,19 @@ class Visual_front(nn.Module):
         self.sentence_encoder = nn.GRU(512, 512, 2, bidirectional=True, dropout=0.3)
         self.fc = nn.Linear(1024, 512)
 
+    def front(self, x):
+        """The 3-D front-end (visual_front.py:11-14,25-27): x (B, T, H, W, 1) channels-last clip -> (B*T, H/4, W/4, 64)
+        pooled feature maps, frames flattened for free."""
+        B, T = x.shape[0], x.shape[1]
+        f, stats = ops.conv3d_stem(x, self.frontend[0].weight)                       # (B,T,H/2,W/2,64)
+        # BatchNorm3d -> PReLU -> MaxPool3d in one pass
+        return ops.bn_act_maxpool3(f.view(B * T, f.shape[2], f.shape[3], 64), self.frontend[1], self.frontend[2],
+                                   stats=stats)
+
     def forward(self, x):
         """x: (B, 1, T, H, W) video.  Returns phonemes (B, T, 512) and sentence features (B, 512, T)."""
         B, _, T, H, W = x.shape
-        f, stats = ops.conv3d_stem(x.reshape(B, T, H, W, 1), self.frontend[0].weight)   # (B,T,H/2,W/2,64)
-        # BatchNorm3d -> PReLU -> MaxPool3d in one pass; frames flattened for free (channels-last)
-        f = ops.bn_act_maxpool3(f.view(B * T, f.shape[2], f.shape[3], 64), self.frontend[1], self.frontend[2],
-                                stats=stats)
+        f = self.front(x.reshape(B, T, H, W, 1))
         f = self.resnet(f)                                                           # (B*T, 512)
         f = ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
         sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)
