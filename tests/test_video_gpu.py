@@ -36,3 +36,33 @@ def test_build_tensor_matches_oracle():
     # the grey levels behind the floats are Pillow's integers
     lvl = np.rint((out2[1, 0, 0] * V.STD + V.MEAN) * 255)
     assert np.array_equal(lvl, np.rint((ref2[0, 0] * V.STD + V.MEAN) * 255))
+
+
+@gpu
+def test_prefetcher_matches_synchronous_path():
+    """The double-buffered pinned-copy + side-stream pipeline hands out exactly the tensors the synchronous call
+    produces for the same draws, in order, with device-side window sampling, while the consumer keeps its stream busy."""
+    import random
+    from vcagan_amd import video
+    dev = torch.device('cuda', 0)
+    vt = video.VideoTransform(dev)
+    B, Tin, W = 3, 9, 5
+    batches = [(_frames(B, Tin, seed=10 + i), [9, 7 + (i % 2), 6]) for i in range(5)]
+    random.seed(123)
+    pf = video.VideoPrefetcher(iter(batches), vt, max_t=W, window=W, augment=True, depth=2)
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for out, lens, meta in pf:
+        busy = busy @ busy * 1e-3                     # work on the consumer's stream between batches
+        got.append((out.clone(), lens, meta))
+    assert len(got) == len(batches)
+    for (fr, n), (out, lens, meta) in zip(batches, got):
+        assert lens == [W] * B and all(0 <= s <= k - W for s, k in zip(meta['start'], n))
+        ref = vt(torch.from_numpy(fr).to(dev), lens, W, meta['flip'], meta['erase'], meta['start'])
+        assert torch.equal(out, ref)
+    # whole clips (validation path): lengths pass through, frames behind them are zero
+    pf2 = video.VideoPrefetcher(iter(batches[:2]), vt, max_t=Tin, window=None, augment=False)
+    out, lens, meta = next(pf2)
+    assert lens == [9, 7, 6] and meta['start'] is None
+    assert torch.equal(out, vt(torch.from_numpy(batches[0][0]).to(dev), lens, Tin))
+    assert float(out[1, :, 7:].abs().max()) == 0.0

@@ -97,3 +97,80 @@ def draw_window(num_frames, window_size):
     st = random.randint(0, num_frames - window_size)
     vid_2_aud = 16000 / 25 / 160
     return st, int(st * vid_2_aud), int(window_size * vid_2_aud)
+
+
+class VideoPrefetcher:
+    """Feeds VideoTransform one batch ahead of the training step: the role of DataLoader(pin_memory=True) +
+    `vid.cuda()` in the reference loop (train.py:139-146,173), with extract_window's sampling (vid_aud_grid.py:172-188)
+    done on the device through the transform kernel's per-clip start offsets.
+
+    `source` yields (frames, n_frames): decoded RGB clips as one uint8 array (B, Tin, H0, W0, 3) on the host and the
+    number of valid frames of each clip.  Per batch the host draws the window starts and the augmentations, copies
+    the frames into one of `depth` pinned staging buffers, and on a side stream issues the host-to-device copy and the
+    transform kernel; iteration hands out the finished (B, 1, T, 112, 112) tensor after making the consumer's stream
+    wait for that work, and immediately stages the next batch, so copy and transform overlap the step that is
+    running.  `window`: frames per training window (train.py:43 window_size), or None for whole clips padded to
+    `max_t` (the validation path)."""
+
+    def __init__(self, source, transform, max_t, window=None, augment=False, depth=2):
+        assert depth >= 2
+        self.src = iter(source)
+        self.vt, self.max_t, self.window, self.augment = transform, max_t, window, augment
+        self.side = torch.cuda.Stream(device=transform.device)
+        self.slots = [dict(pinned=None, dev=None, copied=None) for _ in range(depth)]
+        self.queue = []          # staged batches in order: (tensor, lens, meta, ready event)
+        self.k = 0
+        self.done = False
+        for _ in range(depth - 1):
+            self._stage()
+
+    def _stage(self):
+        if self.done:
+            return
+        try:
+            frames, n_frames = next(self.src)
+        except StopIteration:
+            self.done = True
+            return
+        frames = torch.as_tensor(frames)
+        assert frames.dtype == torch.uint8 and frames.dim() == 5
+        B = frames.shape[0]
+        if self.window is not None:
+            start = [random.randint(0, int(n) - self.window) for n in n_frames]     # extract_window
+            lens = [self.window] * B
+        else:
+            start, lens = None, [int(n) for n in n_frames]
+        flip, erase = draw_augmentations(B, self.augment)
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        if slot['copied'] is not None:
+            slot['copied'].synchronize()             # the copy that last read this pinned buffer has finished
+        if slot['pinned'] is None or slot['pinned'].shape != frames.shape:
+            slot['pinned'] = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
+            slot['dev'] = torch.empty(frames.shape, dtype=torch.uint8, device=self.vt.device)
+        slot['pinned'].copy_(frames)
+        # the device staging buffer is only ever touched on the side stream, so stream order protects its reuse and
+        # nothing here waits for the consumer's stream (that wait would serialise the copy behind the running step)
+        with torch.cuda.stream(self.side):
+            slot['dev'].copy_(slot['pinned'], non_blocking=True)
+            slot['copied'] = torch.cuda.Event()
+            slot['copied'].record(self.side)
+            out = self.vt(slot['dev'], lens, self.max_t, flip, erase, start)
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        self.queue.append((out, lens, dict(flip=flip, erase=erase, start=start), ready))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.queue:
+            self._stage()
+        if not self.queue:
+            raise StopIteration
+        out, lens, meta, ready = self.queue.pop(0)
+        cur = torch.cuda.current_stream(self.vt.device)
+        cur.wait_event(ready)
+        out.record_stream(cur)
+        self._stage()                                # the next batch's copy + transform overlap the caller's step
+        return out, lens, meta
