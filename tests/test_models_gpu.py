@@ -126,8 +126,9 @@ def test_step_matches_reference(variant, prec):
             # outputs 3.9e-2, mel-L1 4.5e-3, gradients 0.17 / 0.20 (GRID / LRS); bounds = about twice that.
             check_step(m, res, g, s, loss_rtol=1.5e-3, out_atol=8e-2, grad_rel=0.4, param_p90=2.1e-4, skip_grads=D)
         else:
-            # bf16x3 / mixed measured: loss 3.0e-4 / 1.7e-3, outputs 6.4e-2, mel-L1 8.6e-3, gradients 0.19 / 0.26
-            check_step(m, res, g, s, loss_rtol=3e-3, out_atol=0.13, grad_rel=0.5, param_p90=2.1e-4, skip_grads=D)
+            # bf16x3 / mixed measured over several runs: loss 3.0e-4 .. 1.7e-3, outputs 6.4e-2 .. 8.3e-2,
+            # mel-L1 8.6e-3 .. 1.0e-2, gradients 0.19 .. 0.29
+            check_step(m, res, g, s, loss_rtol=3e-3, out_atol=0.17, grad_rel=0.55, param_p90=2.1e-4, skip_grads=D)
 
 
 @gpu

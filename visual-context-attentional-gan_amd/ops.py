@@ -1404,7 +1404,7 @@ class GruLayerFn(torch.autograd.Function):
         d_gh = [torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32) for _ in range(2)]
         w_hh = [wts[1], wts[5]]
         dh_gemm, dh_dir = [None, None], [None, None]
-        ns = _nsplit()
+        ns = _nsplit(True)      # 'mixed': single bf16 products in the backward recurrence, like every other gradient
         for s in range(T):
             t0, t1 = T - 1 - s, s
             nd = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
