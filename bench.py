@@ -71,7 +71,7 @@ def roofline_probe(device, dtype):
     ach = flops / dt / 1e12                         # algorithmic (fp32-equivalent) rate
     issued = ach * MFMA_PER_PRODUCT[dtype]          # matrix-core work actually issued (3 bf16 MFMAs per product)
     kern = 'conv_f32_fwd_kernel<128,2,2>' if dtype == 'fp32' else \
-        'conv_bf16_halo_kernel<128,2,2,%d,1>' % MFMA_PER_PRODUCT[dtype]
+        'conv_bf16_halo_kernel<128,2,2,%d>' % MFMA_PER_PRODUCT[dtype]
     # `traffic` is NOT measured by this run: it is the fabric-side byte count of one launch of this kernel on this
     # layer from separate rocprofv3 --pmc passes, 2 x FETCH_SIZE (gfx950 counts 128-byte reads at 64) + WRITE_SIZE;
     # `traffic_source` names the committed profile.  Algorithmic bytes (input + packed weights + output, each once)

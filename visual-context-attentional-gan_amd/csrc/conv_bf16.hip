@@ -1,4 +1,5 @@
-// Split-bf16 implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (forward / input gradient).
+// Split-bf16 implicit-GEMM convolution for gfx950: forward / input gradient on v_mfma_f32_16x16x32_bf16, weight
+// gradients on v_mfma_f32_32x32x16_bf16.
 //
 // Precision: every fp32 operand v is split as v = hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is
 // accumulated in fp32 as hi*hi + hi*lo + lo*hi ("bf16x3", ~2^-17 relative error per product, which keeps the
@@ -10,8 +11,8 @@
 // ((TW-1)*stride+KW) positions is staged in LDS once (fp32 -> prologue -> hi/lo bf16) and reused by every
 // filter tap: the A fragment of tap (kh,kw) is the same LDS image read at a shifted position, so activation
 // traffic from L2 does not scale with the number of taps.  The weights of one (tap, slice) are streamed through
-// a double-buffered LDS tile.  LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with
-// (row >> 2) & 3 so that ds_read_b128 of 16 consecutive rows is conflict-free.
+// a double-buffered LDS tile.  LDS rows are 64 B (32 bf16) with XOR-swizzled 16-byte chunks (the swizzle depends on
+// the kernel's fragment shape, see below) so that the fragment reads are free of bank conflicts.
 #include <mutex>
 #include <unordered_map>
 
@@ -67,95 +68,86 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = *reinterpret_cast<uint4*>(&l);
 }
 
-// TPS = filter taps per pipeline stage (one barrier per stage); every launch uses 1.  Measured and rejected for the
-// single product (NSPLIT = 1, 8 MFMAs per wave and tap at BN = 128): 3 / 6 / 12 taps per stage, a ring of three
-// weight buffers requested two stages ahead, 256 output channels per workgroup, and fetching the next slice's halo a
-// stage ahead into registers - none moved the 128-channel launches by more than 3 % and the narrow ones lost up to
-// 40 % through LDS residency.  With the halo loads removed altogether the launch is only 17-19 % shorter.
+// Matrix instruction: v_mfma_f32_16x16x32_bf16.  One instruction covers the whole 32-channel slice of a 16 x 16
+// output tile (lane l feeds row / column l%16 with the 8 channels of 16-byte chunk l/16), so a (tap, slice) step of
+// a 64 x 64 wave tile is 16 MFMAs of 16 cycles.  The 32x32x16 form (8 MFMAs of 32 cycles, the same LDS traffic,
+// cycles and accumulator registers) was this kernel's first version: on this part the 16x16x32 form holds a higher
+// clock under load, and the same loop ran 8 % (split product) to 22 % (single product) faster summed over the layers
+// of a training step.  The LDS images use the chunk swizzle c ^ (((row >> 2) & 1) << 1), which makes this
+// lane -> (row, chunk) pattern conflict-free for ds_read_b128 over any 16 consecutive rows.
 //
-// Inside a stage the (tap, 16-channel half) steps are software-pipelined by hand: the LDS fragments of step s+1 are
-// requested before the MFMAs of step s are issued (two register sets), so a wave's matrix pipe does not idle for an
-// LDS round trip after every 4..12 MFMAs.  (Fetching the next slice's halo into registers a stage ahead was measured
-// too: no gain, 48 more live registers; the loads of a slice are issued before the barrier that frees the LDS image
-// and converted behind it.)
-template <int BN, int WM, int WN, int NSPLIT, int TPS>
+// Measured on the 32x32x16 version and rejected (none moved the 128-channel launches by more than 3 %, the narrow
+// ones lost up to 40 % through LDS residency): 3 / 6 / 12 filter taps per barrier for the single product, a ring of
+// three weight buffers requested two taps ahead, 256 output channels per workgroup, register double-buffered
+// fragments, fetching the next slice's halo a stage ahead into registers.  Timing probes: without the halo loads a
+// launch is 17-19 % shorter, without the weight tiles 11-14 %.
+__device__ __forceinline__ int sw16(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int BN, int WM, int WN, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
-  constexpr int BROW = (NSPLIT == 3) ? 128 : 64;  // bytes of one packed weight row that are used
-  constexpr int BTAP = BN * BROW;                 // bytes of one tap's weight tile
-  constexpr int BBUF = TPS * BTAP;                // bytes of one weight LDS buffer (a stage)
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
+  constexpr int BROW = (NSPLIT == 3) ? 128 : 64;
+  constexpr int BBUF = BN * BROW;
 
   const vca_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int lr = lane & 31, lh = lane >> 5;
+  const int lr = lane & 15, lc = lane >> 4;
   const int npos_total = a.NI * a.NPOS;
   unsigned char* halo_hi = smem;
   unsigned char* halo_lo = smem + npos_total * 64;
   unsigned char* bbase = smem + npos_total * 64 * (NSPLIT == 3 ? 2 : 1);
 
-  const int sid0 = blockIdx.x * a.NI;   // first sub-patch of this workgroup
+  const int sid0 = blockIdx.x * a.NI;
   const int n0 = blockIdx.y * BN;
   const int He = d.Hin << d.ups, We = d.Win << d.ups;
   const int tpix = a.TH * a.TW;
 
-  // halo base position of this lane's MT accumulator rows
   int hb[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = wm * WTM + i * 32 + lr;
+    const int m = wm * WTM + i * 16 + lr;
     const int img = m / tpix, rem = m - img * tpix;
     const int ty = rem / a.TW, tx = rem - ty * a.TW;
     hb[i] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
   }
-  // byte offset of this lane's weight-fragment rows inside a tap's tile (first 16-channel half; the second is ^ 32)
   int boff[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int row = wn * WTN + j * 32 + lr;
-    boff[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    const int row = wn * WTN + j * 16 + lr;
+    boff[j] = row * 64 + ((lc ^ sw16(row)) << 4);
   }
 
-  f32x16 acc[MT][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  // Weight tiles go from global memory straight into LDS (global_load_lds_dwordx4: no registers, no ds_write).
-  // One wave-instruction fills 1 KiB = 16 rows x 64 B of the hi or lo image in lane order, so the XOR swizzle of
-  // the image is applied to the per-lane SOURCE address: lane l -> row 16*piece + l/4, slot l%4 holds source
-  // chunk (l%4) ^ ((row>>2)&3).
-  constexpr int NPIECE = BN * BROW / 1024;            // per tap: 16 (BN=128, split) ... 2 (BN=32, single)
-  constexpr int SPIECE = NPIECE * TPS;                // per stage
-  constexpr int PPW = (SPIECE + 3) / 4;               // pieces per wave
+  constexpr int NPIECE = BN * BROW / 1024;
+  constexpr int PPW = (NPIECE + 3) / 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int nstage = (a.ntaps + TPS - 1) / TPS;
-  auto issue_b = [&](int stage, int chunk, int buf) {
+  auto issue_b = [&](int tap, int chunk, int buf) {
+    const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad) * 128;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int si = wave_u * PPW + i;
-      const int tt = si / NPIECE, pi = si - tt * NPIECE;
-      const int tap = stage * TPS + tt;
-      if (si < SPIECE && tap < a.ntaps) {
-        const unsigned char* src = a.w + ((size_t)(tap * a.nchunk + chunk) * a.npad) * 128;
+      const int pi = wave_u * PPW + i;
+      if (pi < NPIECE) {
         const int part = pi / (BN / 16), pr = pi - part * (BN / 16);
         const int row = pr * 16 + (lane >> 2), slot = lane & 3;
-        const int grow = min(n0 + row, a.npad - 1);    // rows past the packed matrix feed columns that are never stored
-        const unsigned char* g = src + (size_t)grow * 128 + part * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-        unsigned char* l = bbase + buf * BBUF + tt * BTAP + part * (BN * 64) + pr * 1024;
+        const int grow = min(n0 + row, a.npad - 1);
+        const unsigned char* g = src + (size_t)grow * 128 + part * 64 + ((slot ^ sw16(row)) << 4);
+        unsigned char* l = bbase + buf * BBUF + part * (BN * 64) + pr * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
     }
   };
-  // the tiles requested at the start of a stage must have landed before the barrier that ends the stage
   auto wait_b = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  // Halo staging plan of this thread, the same for every channel slice: up to 3 (position, 16-channel half) items
-  // with the element offset of the source pixel (-1: padding / outside the image / dilation hole).
+
   constexpr int NHI = (2 * MAXPOS + 255) / 256;
   long long hsrc[NHI];
 #pragma unroll
@@ -182,9 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     }
   }
 
-  // ---- halo of one 32-channel slice: global memory -> registers (fetch), registers -> hi/lo bf16 in LDS (store)
-  float4 pre[NHI][4];
-  auto fetch_halo = [&](int chunk) {
+  auto stage_halo = [&](int chunk) {
+    float4 pre[NHI][4];
 #pragma unroll
     for (int k = 0; k < NHI; ++k) {
       const int it = tid + k * 256;
@@ -205,8 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
         }
       }
     }
-  };
-  auto store_halo = [&](int chunk) {
+    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
 #pragma unroll
     for (int k = 0; k < NHI; ++k) {
       const int it = tid + k * 256;
@@ -217,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
       for (int q = 0; q < 4; ++q) {
         v[4 * q] = pre[k][q].x; v[4 * q + 1] = pre[k][q].y; v[4 * q + 2] = pre[k][q].z; v[4 * q + 3] = pre[k][q].w;
       }
-      if ((a.in_scale || d.act) && hsrc[k] >= 0) {   // BN-affine / activation prologue; padding stays zero
+      if ((a.in_scale || d.act) && hsrc[k] >= 0) {
         const int ci0 = chunk * 32 + half * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -230,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
           }
         }
       }
-      const int sw = (pos >> 2) & 3;
+      const int sw = sw16(pos);
       uint4 h0, l0, h1, l1;
       split8(v, h0, l0);
       split8(v + 8, h1, l1);
@@ -245,102 +235,60 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     }
   };
 
-  // ---- fragments of one (tap, 16-channel half) step and their products
-  struct Frag {
-    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
-  };
-  auto load_frags = [&](Frag& f, int tapoff, const unsigned char* btile, int ks) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int pa = hb[i] + tapoff;
-      const int off = (pa * 64 + ((lh ^ ((pa >> 2) & 3)) << 4)) ^ (ks << 5);
-      f.ah[i] = *reinterpret_cast<const bf16x8*>(halo_hi + off);
-      if (NSPLIT == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(halo_lo + off);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int off = boff[j] ^ (ks << 5);
-      f.bh[j] = *reinterpret_cast<const bf16x8*>(btile + off);
-      if (NSPLIT == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(btile + BN * 64 + off);
-    }
-  };
-  auto mma = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (NSPLIT == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-      }
-  };
-
   const int cpz = (a.nchunk + a.ksplit - 1) / a.ksplit;
   const int chunk_beg = blockIdx.z * cpz, chunk_end = min(a.nchunk, chunk_beg + cpz);
   for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
-    fetch_halo(chunk);
-    __syncthreads();  // every wave is done with the previous slice's halo and weight buffers
-    store_halo(chunk);
+    stage_halo(chunk);
     issue_b(0, chunk, 0);
     wait_b();
     __syncthreads();
 
-    int kh = 0, kw = 0;   // filter tap the next stage starts at
-    auto compute_stage = [&](int stage) {
-      const unsigned char* bst = bbase + (stage & 1) * BBUF;
-      int toff[TPS];
+    int kh = 0, kw = 0;
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int buf = tap & 1;
+      if (tap + 1 < a.ntaps) issue_b(tap + 1, chunk, buf ^ 1);
+      const int tapoff = kh * a.HW + kw;
+      if (++kw == d.KW) { kw = 0; ++kh; }
+      const unsigned char* bt = bbase + buf * BBUF;
+      bf16x8 bh[NT], bl[NT];
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) {
-        toff[tt] = kh * a.HW + kw;
-        if (++kw == d.KW) { kw = 0; ++kh; }
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(bt + boff[j]);
+        if (NSPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bt + BN * 64 + boff[j]);
       }
-      const int ntap_here = min(TPS, a.ntaps - stage * TPS);
-      if (TPS == 1 || ntap_here == TPS) {
-        Frag f[2];
-        load_frags(f[0], toff[0], bst, 0);
 #pragma unroll
-        for (int s2 = 0; s2 < 2 * TPS; ++s2) {
-          if (s2 + 1 < 2 * TPS) load_frags(f[(s2 + 1) & 1], toff[(s2 + 1) >> 1], bst + ((s2 + 1) >> 1) * BTAP, (s2 + 1) & 1);
-          mma(f[s2 & 1]);
-        }
-      } else {
+      for (int i = 0; i < MT; ++i) {
+        const int pa = hb[i] + tapoff;
+        const int off = pa * 64 + ((lc ^ sw16(pa)) << 4);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(halo_hi + off);
+        bf16x8 al;
+        if (NSPLIT == 3) al = *reinterpret_cast<const bf16x8*>(halo_lo + off);
 #pragma unroll
-        for (int tt = 0; tt < TPS; ++tt) {
-          if (tt < ntap_here) {
-            Frag f[2];
-            load_frags(f[0], toff[tt], bst + tt * BTAP, 0);
-            load_frags(f[1], toff[tt], bst + tt * BTAP, 1);
-            mma(f[0]);
-            mma(f[1]);
+        for (int j = 0; j < NT; ++j) {
+          if (NSPLIT == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
           }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
         }
       }
-    };
-    for (int stage = 0; stage + 1 < nstage; ++stage) {
-      issue_b(stage + 1, chunk, (stage & 1) ^ 1);
-      compute_stage(stage);
       wait_b();
       __syncthreads();
     }
-    compute_stage(nstage - 1);
-    wait_b();
-    __syncthreads();
   }
 
-  // ---- epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue: D[row][col]: col = lane&15, row = 4*(lane>>4) + r
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + lr;
+    const int n = n0 + wn * WTN + j * 16 + lr;
     const bool nv = n < d.Cout;
     const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      for (int r = 0; r < 4; ++r) {
+        const int m = wm * WTM + i * 16 + 4 * lc + r;
         const int img = m / tpix, rem = m - img * tpix;
         const int ty = rem / a.TW, tx = rem - ty * a.TW;
         int nn, oy0, ox0;
@@ -362,9 +310,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
       }
     }
     if (a.stats) {
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (nv && lh == 0) {
+      if (nv && lc == 0) {
         atomicAdd(a.stats + n, s1);
         atomicAdd(a.stats + d.Cout + n, s2);
       }
@@ -1016,10 +966,10 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Co
   return best;
 }
 
-template <int BN, int WM, int WN, int NSPLIT, int TPS>
+template <int BN, int WM, int WN, int NSPLIT>
 int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
-  auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT, TPS>;
-  const size_t lds = halo + 2 * (size_t)TPS * BN * (NSPLIT == 3 ? 128 : 64);
+  auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
+  const size_t lds = halo + 2 * (size_t)BN * (NSPLIT == 3 ? 128 : 64);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1198,8 +1148,8 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
 #define LAUNCH_H(BN_, WM_, WN_)                                                                   \
   do {                                                                                             \
     const int gy = (d->Cout + BN_ - 1) / BN_;                                                      \
-    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3, 1>(a, gx, gy, halo, s)                      \
-                       : launch_halo<BN_, WM_, WN_, 1, 1>(a, gx, gy, halo, s);                     \
+    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3>(a, gx, gy, halo, s)                         \
+                       : launch_halo<BN_, WM_, WN_, 1>(a, gx, gy, halo, s);                        \
   } while (0)
   if (d->Cout > 64) LAUNCH_H(128, 2, 2);
   else if (d->Cout > 32) LAUNCH_H(64, 2, 2);
