@@ -65,7 +65,9 @@ def _check_step(ref, hip, want, got, loss_rtol, out_atol, grad_rel):
 # (precision, activation atol, loss rtol, gradient relative L2).  The generator-side losses are taken after the
 # discriminators' first Adam update (~lr * sign(grad) per weight), which amplifies last-bit differences of the
 # D-phase gradients: measured up to 1.2e-4 relative on g_loss in fp32 at T = 150, so the fp32 loss bound is 2e-4.
-PREC = [('fp32', 2e-4, 2e-4, 5e-2), ('bf16x3', 3e-3, 5e-4, 0.15)]
+# Activations: the maximum runs over up to 96 000 mel bins per output here (T = 150) against 3 200 in the golden
+# cases, and fp32 sums are accumulated in a different order than on the CPU: measured up to 2.2e-4, bound 4e-4.
+PREC = [('fp32', 4e-4, 2e-4, 5e-2), ('bf16x3', 3e-3, 5e-4, 0.15)]
 
 
 @gpu

@@ -404,7 +404,6 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   for (int t = 0; t < MAXSLOT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
   // Staging plan, the same for every patch: which (slot, halo row, halo column) each of this thread's halo items
   // covers and which output pixel its output-gradient item covers.  Only the slots' image / origin change from
   // patch to patch; they are worked out once per patch by the first NI threads (slot_info).
@@ -646,24 +645,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
   const int He = d.Hin << d.ups, We = d.Win << d.ups;
   const int tpix = a.TH * a.TW;
 
-  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-  const int col = 16 * (g & 1) + 4 * p;
-  const int kq = 8 * (g >> 1) + q;
-  const int colchunk = col >> 3, colbyte = (col & 7) * 2;
-  int pk[16];
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;   // transposed-read geometry of this lane
+  // v_mfma_f32_16x16x32_bf16: the 32 x 32 quadrant of a tap is 2 x 2 tiles of 16 x 16 and a step reduces 32 pixels; lane l
+  // feeds row / column l%16 with the 8 pixels 8*(l/16).. of the step (two transposed reads of 4 pixels each).  7 %
+  // faster than the 32x32x16 form here (the chip holds a higher clock on it); the 8-wave kernel above lost 8 % with it.
+  const int kq16 = 8 * g + q, c16sel = p >> 1, c16byte = (p & 1) * 8;
+  int pk16[8];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int k = (s >> 1) * 16 + kq + 4 * (s & 1);
+  for (int s = 0; s < 8; ++s) {
+    const int k = (s >> 1) * 32 + kq16 + 4 * (s & 1);
     const int img = k / tpix, rem = k - img * tpix;
     const int ty = rem / a.TW, tx = rem - ty * a.TW;
-    pk[s] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
+    pk16[s] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
   }
-
-  f32x16 acc[MAXT];
+  f32x4 acc16[MAXT][2][2];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[t][i >> 1][i & 1][r] = 0.f;
 
   const unsigned char* my_hh = halo_hi + cih * npos_total * 64;
   const unsigned char* my_hl = halo_lo + cih * npos_total * 64;
@@ -762,55 +763,73 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
     }
     __syncthreads();
 
+    {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      bf16x8 bh[4], bl[4];
+      bf16x8 bh[2][2], bl[2][2];              // [32-pixel step][co half of the quadrant]
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int k0 = (hf * 4 + kk) * 16 + kq, k1 = k0 + 4;
-        const int o0 = k0 * 64 + ((colchunk ^ ((k0 >> 2) & 3)) << 4) + colbyte;
-        const int o1 = k1 * 64 + ((colchunk ^ ((k1 >> 2) & 3)) << 4) + colbyte;
-        bh[kk] = tr_read8(my_gh + o0, my_gh + o1);
-        if (NSPLIT == 3) bl[kk] = tr_read8(my_gl + o0, my_gl + o1);
+      for (int st = 0; st < 2; ++st) {
+        const int k0 = (hf * 2 + st) * 32 + kq16, k1 = k0 + 4;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int o0 = k0 * 64 + (((2 * ch + c16sel) ^ ((k0 >> 2) & 3)) << 4) + c16byte;
+          const int o1 = k1 * 64 + (((2 * ch + c16sel) ^ ((k1 >> 2) & 3)) << 4) + c16byte;
+          bh[st][ch] = tr_read8(my_gh + o0, my_gh + o1);
+          if (NSPLIT == 3) bl[st][ch] = tr_read8(my_gl + o0, my_gl + o1);
+        }
       }
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         if (t < a.ntaps) {
           const int kh = t / d.KW, kw = t - kh * d.KW;
           int tapoff = kh * a.HW + kw;
-          // keeps the 72 per-(tap, slice) LDS addresses from being hoisted out of the patch loop into registers
           asm volatile("" : "+s"(tapoff));
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int ks = hf * 4 + kk;
-            const int p0 = pk[2 * ks] + tapoff, p1 = pk[2 * ks + 1] + tapoff;
-            const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
-            const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
-            const bf16x8 ah = tr_read8(my_hh + o0, my_hh + o1);
-            if (NSPLIT == 3) {
-              const bf16x8 al = tr_read8(my_hl + o0, my_hl + o1);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[t], 0, 0, 0);
+          for (int st = 0; st < 2; ++st) {
+            const int s32 = hf * 2 + st;
+            const int p0 = pk16[2 * s32] + tapoff, p1 = pk16[2 * s32 + 1] + tapoff;
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+              const int o0 = p0 * 64 + (((2 * ih + c16sel) ^ ((p0 >> 2) & 3)) << 4) + c16byte;
+              const int o1 = p1 * 64 + (((2 * ih + c16sel) ^ ((p1 >> 2) & 3)) << 4) + c16byte;
+              const bf16x8 ah = tr_read8(my_hh + o0, my_hh + o1);
+              bf16x8 al;
+              if (NSPLIT == 3) al = tr_read8(my_hl + o0, my_hl + o1);
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch) {
+                if (NSPLIT == 3) {
+                  acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[st][ch], acc16[t][ih][ch], 0, 0, 0);
+                  acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[st][ch], acc16[t][ih][ch], 0, 0, 0);
+                }
+                acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[st][ch], acc16[t][ih][ch], 0, 0, 0);
+              }
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc[t], 0, 0, 0);
           }
         }
       }
     }
+    }
   }
 
-  // ---- accumulate into dW: D[row = ci][col = co]
-  const int lr = lane & 31, lh = lane >> 5;
-  const int co = co_base + coh * 32 + lr;
+  {
+  // ---- accumulate into dW: 16 x 16 tiles, col = lane&15, row = 4*(lane>>4) + r
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    if (t < a.ntaps && co < d.Cout) {
+    if (t < a.ntaps) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci_base + cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < d.Cin) atomicAdd(a.dw + ((size_t)t * d.Cin + ci) * a.Cout4 + co, acc[t][r]);
-      }
+      for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int co = co_base + coh * 32 + ch * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = ci_base + cih * 32 + ih * 16 + 4 * g + r;
+            if (ci < d.Cin && co < d.Cout)
+              atomicAdd(a.dw + ((size_t)t * d.Cin + ci) * a.Cout4 + co, acc16[t][ih][ch][r]);
+          }
+        }
     }
+  }
   }
 }
 
@@ -1057,12 +1076,12 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[6] = {reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
+    const void* ks[6] = {reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<3>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<1>),
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
                          reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, false>),
                          reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, true>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<3>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<1>)};
+                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>)};
     for (int i = 0; i < 6; ++i) {
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
