@@ -39,7 +39,8 @@ class Mode(torch.utils._python_dispatch.TorchDispatchMode):
         if not any(v in name for v in VIEWS):
             fr = [f for f in traceback.extract_stack() if ('visual-context' in f.filename or 'vcagan' in f.filename)
                   and 'aten_sites' not in f.filename]
-            key = name + ' @ ' + (' <- '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in fr[-3:]) or '(autograd engine)')
+            key = name + ' @ ' + (' <- '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in fr[-3:]) or
+                                  '(autograd engine) ' + str([tuple(a.shape) for a in args if torch.is_tensor(a)][:1]))
             n = max([a.numel() for a in args if torch.is_tensor(a)] + [0])
             sites[key] += 1
             elems[key] += n

@@ -100,11 +100,11 @@ class GenResBlk(nn.Module):
         t = (w.view(co, ci, 1, 1, 5, 5) * A.view(1, 1, 2, 3, 5, 1)).sum(4)                 # (co, ci, py, a, kw)
         t = (t.view(co, ci, 2, 3, 1, 1, 5) * A.view(1, 1, 1, 1, 2, 3, 5)).sum(6)           # (co, ci, py, a, px, b)
         w3 = t.permute(2, 4, 0, 1, 3, 5).reshape(4 * co, ci, 3, 3)
+        s, _, x = ops.conv2d_skip(x, self.conv1x1.weight, 1, 0)      # shortcut first: see forward()
         a = ops.bn_act(x, self.norm1, ops.LEAKY)
         y4 = ops.conv2d(a, w3, self.conv1.bias.repeat(4), 1, 1)                             # (B, H, W, (py, px, co))
         r = y4.view(B, H, W, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, co)
         r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
-        s = _conv(x, self.conv1x1)
         s = s.view(B, H, 1, W, 1, co).expand(B, H, 2, W, 2, co).reshape(B, 2 * H, 2 * W, co)
         return ops.add_scale(r, s, _RSQRT2)
 
@@ -112,13 +112,19 @@ class GenResBlk(nn.Module):
         if self.upsample and SUBPIXEL_UPSAMPLE:
             return self._forward_subpixel(x)
         ups = 1 if self.upsample else 0
+        s = None
+        if self.learned_sc and not ups:
+            # the block input feeds the shortcut convolution and the batch-norm branch: taking the latter from the
+            # convolution's alias output lets its input-gradient kernel add the branch's gradient in its epilogue
+            s, _, x = ops.conv2d_skip(x, self.conv1x1.weight, 1, 0)
         r, st = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups, want_stats=True)   # nearest x2 read inside the conv
         r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY, stats=st), self.conv2)
-        if self.learned_sc:
-            s = _conv(x, self.conv1x1, ups)
-        else:
-            assert not ups
-            s = x
+        if s is None:
+            if self.learned_sc:
+                s = _conv(x, self.conv1x1, ups)
+            else:
+                assert not ups
+                s = x
         return ops.add_scale(r, s, _RSQRT2)
 
     def forward_tiled(self, x, nz):
@@ -134,14 +140,14 @@ class GenResBlk(nn.Module):
         ax, an = ops.bn_act_parts([(x, H), (nz, 1)], self.norm1, ops.LEAKY)
         w1 = self.conv1.weight
         kh, kw = w1.shape[2], w1.shape[3]
-        w_rows = w1[:, :C1].permute(2, 0, 1, 3).reshape(kh * co, C1, 1, kw)
+        w_rows = ops.param_view(w1, lambda t: t[:, :C1].permute(2, 0, 1, 3), (kh * co, C1, 1, kw))
         p = ops.conv2d(ax.view(B, 1, W, C1), w_rows, None, 1, (0, kw // 2))           # (B, 1, W, kh*co)
-        r = ops.conv2d(an, w1[:, C1:].contiguous(), self.conv1.bias, 1, (kh // 2, kw // 2))
+        r = ops.conv2d(an, ops.param_view(w1, lambda t: t[:, C1:]), self.conv1.bias, 1, (kh // 2, kw // 2))
         r = ops.hband_expand(p.view(B, W, kh * co), H, kh, kh // 2, base=r)
         r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY), self.conv2)
         wsc = self.conv1x1.weight
-        s = ops.conv2d(nz, wsc[:, C1:].contiguous(), None, 1, 0)
-        s = ops.hband_expand(ops.linear(x, wsc[:, :C1, 0, 0].contiguous()), H, 1, 0, base=s)
+        s = ops.conv2d(nz, ops.param_view(wsc, lambda t: t[:, C1:]), None, 1, 0)
+        s = ops.hband_expand(ops.linear(x, ops.param_view(wsc, lambda t: t[:, :C1, 0, 0])), H, 1, 0, base=s)
         return ops.add_scale(r, s, _RSQRT2)
 
 
@@ -292,10 +298,11 @@ class Discriminator(nn.Module):
         B, H, W, C = ah.shape
         co, kh, kw = conv.out_channels, conv.kernel_size[0], conv.kernel_size[1]
         wc = conv.weight
-        q = ops.linear(av, wc[:, C:].permute(2, 3, 0, 1).reshape(kh * kw * co, av.shape[-1]))   # (B, kh*kw*co)
+        wq = ops.param_view(wc, lambda t: t[:, C:].permute(2, 3, 0, 1), (kh * kw * co, av.shape[-1]))
+        q = ops.linear(av, wq)                                                                 # (B, kh*kw*co)
         qw = ops.hband_expand(q.view(B * kh, 1, kw * co), W, kw, conv.padding[1])              # (B*kh, W, 1, co)
         qw = qw.view(B, kh, W, co).permute(0, 2, 1, 3).reshape(B, W, kh * co)
-        o = ops.conv2d(ah, wc[:, :C].contiguous(), conv.bias, 1, tuple(conv.padding))
+        o = ops.conv2d(ah, ops.param_view(wc, lambda t: t[:, :C]), conv.bias, 1, tuple(conv.padding))
         return ops.hband_expand(qw, H, kh, conv.padding[0], base=o)
 
     def forward(self, x, c, vid_max_length):

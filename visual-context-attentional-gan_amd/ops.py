@@ -511,6 +511,39 @@ class ConvWgradFn(torch.autograd.Function):
         return gx, ggy, None
 
 
+class ParamViewFn(torch.autograd.Function):
+    """A re-laid-out part of a parameter as a fresh contiguous tensor: y = view_fn(w).reshape(shape), view_fn being
+    pure view operations (slicing, permute).  Used where a layer works on channel groups of a weight separately.
+    Plain autograd would rebuild a full-size gradient per use (a zero fill, a strided copy and an add, each the
+    size of the whole weight); here, while direct_param_grad() is active, the incoming gradient is added straight
+    into the matching view of the parameter's flat gradient."""
+
+    @staticmethod
+    def forward(ctx, w, view_fn, shape):
+        ctx.view_fn, ctx.w = view_fn, w
+        v = view_fn(w.detach())
+        ctx.vshape = v.shape
+        return v.reshape(shape).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.w
+        sink = _grad_sink(w)
+        if sink is not None:
+            ctx.view_fn(sink).add_(g.view(ctx.vshape))
+            return None, None, None
+        full = torch.zeros_like(w)
+        ctx.view_fn(full).copy_(g.reshape(ctx.vshape))
+        return full, None, None
+
+
+def param_view(w, view_fn, shape=None):
+    """view_fn(w) as a contiguous tensor of `shape` (default: the view's own shape); see ParamViewFn."""
+    if shape is None:
+        shape = tuple(view_fn(w.detach()).shape)
+    return ParamViewFn.apply(w, view_fn, tuple(shape))
+
+
 class BnStats:
     """Statistics of a convolution output handed to the batch-norm that follows: sums of (y - bias)."""
 
