@@ -100,9 +100,10 @@ int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const 
                       const float* in_scale, const float* in_shift, const float* in_alpha, const float* res,
                       float* y, float* stats, void* stream);
 /* Split-bf16 variant of vca_conv_wgrad_f32 (same fp32 [tap][Cin][Cout4] output, accumulated with atomics into a
- * zeroed buffer; at most 32 taps). */
+ * zeroed buffer; at most 32 taps).  bias_grad (may be NULL): [Cout] vector to which the column sums of gy, i.e. the
+ * gradient of the convolution's bias, are ADDED (fp32, from the output-gradient tiles the kernel stages anyway). */
 int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, const float* gy, const float* in_scale,
-                        const float* in_shift, const float* in_alpha, float* dwpack, void* stream);
+                        const float* in_shift, const float* in_alpha, float* dwpack, float* bias_grad, void* stream);
 long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps);
 int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream);
 /* vca_pack_weight_bf16 for many weights in one launch (all packed copies of one network after its optimizer step;

@@ -161,3 +161,37 @@ def test_stem_kernel(shape, prec, tol):
     y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().cuda())
     # the weight gradient runs at the same matrix-core precision as the forward pass (patch form of the clip)
     assert rel_err(wd.grad, wr.grad) < (2e-5 if prec == 'bf16x3' else tol)
+
+
+@gpu
+@pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('mixed', 1.5e-2)])
+@pytest.mark.parametrize('case', [(3, 9, 11, 32, 48, 5, 2), (4, 12, 12, 64, 100, 3, 1), (2, 6, 7, 96, 33, 1, 0),
+                                  (2, 20, 13, 64, 64, 5, 2)])
+def test_conv2d_gradients_into_sinks(case, prec, tol):
+    """Parameters that own a preallocated gradient (the flat buffers of a training step) receive the weight gradient
+    through the per-parameter workspace and the bias gradient from the weight-gradient kernel itself (column sums of
+    the output-gradient tiles it stages), both ADDED to what the buffers already hold."""
+    from vcagan_amd import ops
+    ops.set_precision(prec)
+    N, H, W, ci, co, k, pad = case
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(N, H, W, ci, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    wd = torch.nn.Parameter(w.cuda())
+    bd = torch.nn.Parameter(b.cuda())
+    w0, b0 = torch.randn(w.shape, generator=g), torch.randn(co, generator=g)
+    wd.grad, bd.grad = w0.cuda(), b0.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, 1, pad)
+    with ops.direct_param_grad():
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    assert rel_err(bd.grad - b0.cuda(), br.grad) < max(tol / 50, 2e-5)      # fp32 sums whatever the product precision
+    assert rel_err(wd.grad - w0.cuda(), wr.grad) < tol
+    assert rel_err(xd.grad.permute(0, 3, 1, 2), xr.grad) < tol

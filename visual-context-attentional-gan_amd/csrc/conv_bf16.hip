@@ -345,6 +345,7 @@ struct WArgs {
   const float* in_shift;
   const float* in_alpha;
   float* dw;  // fp32 [tap][Cin][Cout4]
+  float* bias_grad;  // optional [Cout]: += column sums of gy (the bias gradient), from the tiles the kernel stages anyway
   int Cout4, ntaps;
   int NI, TH, TW, HH, HW, NPOS;
   int tiles_x, tiles_y, nsub, ntiles, tiles_per_block, co_tiles;
@@ -420,6 +421,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   }
   const int g_m = tid >> 2, g_qt = tid & 3;
   const int g_img = g_m / tpix, g_ty = (g_m - g_img * tpix) / a.TW, g_tx = (g_m - g_img * tpix) - g_ty * a.TW;
+
+  // bias gradient: the workgroups of the first input-channel tile also sum the output-gradient values they stage
+  const bool do_bias = a.bias_grad != nullptr && cit == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int pt_beg = blockIdx.y * a.tiles_per_block;
   const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
@@ -507,6 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
             if (c0 + j < d.Cout) v[j] = src[j];
         }
       }
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+      }
       const int sw = (m >> 2) & 3;
       uint4 h0, l0;
       split8(v, h0, l0);
@@ -584,6 +593,17 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
       }
     }
     }
+  }
+
+  if (do_bias) {   // fold the per-thread sums (thread t holds channels 8*(t&3).. of the 32-channel tile) through LDS
+    float* bsh = reinterpret_cast<float*>(smem);   // the staged images are not needed any more
+    __syncthreads();
+    if (tid < 32) bsh[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&bsh[g_qt * 8 + j], bsum[j]);
+    __syncthreads();
+    if (tid < 32 && co_base + tid < d.Cout) atomicAdd(a.bias_grad + co_base + tid, bsh[tid]);
   }
 
   if constexpr (RR) {
@@ -665,6 +685,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc16[t][i >> 1][i & 1][r] = 0.f;
+
+  // bias gradient: as in the kernel above (thread t stages channels 8*(t&7).. of the 64-channel tile for every pixel)
+  const bool do_bias = a.bias_grad != nullptr && cit == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const unsigned char* my_hh = halo_hi + cih * npos_total * 64;
   const unsigned char* my_hl = halo_lo + cih * npos_total * 64;
@@ -754,6 +778,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
             if (c0 + j < d.Cout) v[j] = src[j];
         }
       }
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+      }
       const int sw = (m >> 2) & 3, qt = oc & 3;
       const int base = (oc >> 2) * BM * 64 + m * 64 + ((qt ^ sw) << 4);
       uint4 h0, l0;
@@ -809,6 +837,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
       }
     }
     }
+  }
+
+  if (do_bias) {
+    float* bsh = reinterpret_cast<float*>(smem);   // the staged images are not needed any more
+    __syncthreads();
+    if (tid < 64) bsh[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&bsh[(tid & 7) * 8 + j], bsum[j]);
+    __syncthreads();
+    if (tid < 64 && co_base + tid < d.Cout) atomicAdd(a.bias_grad + co_base + tid, bsh[tid]);
   }
 
   {
@@ -1016,7 +1055,7 @@ int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
 
 extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, const float* gy,
                                    const float* in_scale, const float* in_shift, const float* in_alpha,
-                                   float* dwpack, void* stream) {
+                                   float* dwpack, float* bias_grad, void* stream) {
   VCA_CHECK_ARG(d && x && gy && dwpack && (nsplit == 1 || nsplit == 3));
   VCA_CHECK_ARG(d->N > 0 && d->D == 1 && d->OD == 1 && d->KD == 1 && d->pad_d == 0 && d->Cin > 1 && d->Cout > 0);
   VCA_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->OH > 0 && d->OW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0);
@@ -1027,6 +1066,7 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   WArgs a;
   a.d = *d;
   a.x = x; a.gy = gy; a.in_scale = in_scale; a.in_shift = in_shift; a.in_alpha = in_alpha; a.dw = dwpack;
+  a.bias_grad = bias_grad;
   a.Cout4 = (d->Cout + 3) & ~3;
   a.ntaps = d->KH * d->KW;
   // at most 9 taps: 64 x 64 tiles, one quadrant per wave

@@ -339,9 +339,13 @@ def colsum(x, c):
     return _colsum_add(x, c, torch.zeros((c,), device=x.device, dtype=torch.float32))
 
 
-def _conv_wgrad_raw(x, gy, cfg, sink=None):
+_bias_done = [False]   # set by _conv_wgrad_raw: whether the launch also accumulated the bias gradient
+
+
+def _conv_wgrad_raw(x, gy, cfg, sink=None, bias_sink=None):
     """Weight gradient in the parameter's layout; with `sink` (a contiguous tensor of that layout) it is added to
-    sink and None is returned."""
+    sink and None is returned.  bias_sink: optional (Cout,) tensor that receives += the bias gradient (column sums
+    of gy); returns False in its place when the kernel in use cannot produce it (the caller then sums itself)."""
     cout, cin, taps = cfg.cout, cfg.cin, cfg.kd * cfg.kh * cfg.kw
     shape = (taps, cin, (cout + 3) // 4 * 4)
     deferred = sink is not None and _direct_grad[0]
@@ -360,9 +364,11 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None):
             dwp = _wgrad_ws[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
     ns = _nsplit(True)
     if ns and cin > 1 and cfg.kd == 1 and taps <= 32:
-        check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
-              'conv_wgrad_bf16')
+        check(_lib.lib().vca_conv_wgrad_bf16(cfg.desc(), ns, ptr(x), ptr(gy), None, None, None, ptr(dwp),
+                                             ptr(bias_sink), stream()), 'conv_wgrad_bf16')
+        _bias_done[0] = bias_sink is not None
     else:
+        _bias_done[0] = False
         check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
               'conv_wgrad')
     if deferred:
@@ -400,8 +406,13 @@ class ConvStatsFn(torch.autograd.Function):
         cfg = ctx.cfg
         gy = _c(gy)
         gx = _conv_dgrad_raw(gy, w, cfg) if ctx.needs_input_grad[0] else None
-        gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w)) if ctx.needs_input_grad[1] else None
-        gb = _bias_grad(gy, ctx.bias_ref, cfg.cout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        bsink = _grad_sink(ctx.bias_ref) if want_b else None
+        _bias_done[0] = False
+        gw = _conv_wgrad_raw(_c(x), gy, cfg, _grad_sink(w), bsink) if ctx.needs_input_grad[1] else None
+        gb = None
+        if want_b and not (bsink is not None and _bias_done[0]):
+            gb = _bias_grad(gy, ctx.bias_ref, cfg.cout)
         return gx, gw, gb, None
 
 
@@ -460,12 +471,15 @@ class ConvFn(torch.autograd.Function):
         _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, w, cfg) if ctx.needs_input_grad[0] else None
         gw = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _inputs_only[0]
+        bsink = _grad_sink(ctx.bias_ref) if want_b else None
+        _bias_done[0] = False
         if ctx.needs_input_grad[1] and not _inputs_only[0]:
             sink = _grad_sink(w)
-            gw = ConvWgradFn.apply(x, gy, cfg) if sink is None else _conv_wgrad_raw(_c(x), gy, cfg, sink)
+            gw = ConvWgradFn.apply(x, gy, cfg) if sink is None else _conv_wgrad_raw(_c(x), gy, cfg, sink, bsink)
         _exact_bwd[0] = False
         gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2] and not _inputs_only[0]:
+        if want_b and not (bsink is not None and _bias_done[0]):
             gb = gy.reshape(-1, cfg.cout).sum(0) if torch.is_grad_enabled() else _bias_grad(gy, ctx.bias_ref, cfg.cout)
         return gx, gw, gb, None
 
