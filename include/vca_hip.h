@@ -49,6 +49,13 @@ typedef struct {
                               3 ReLU; applied after the optional per-channel affine in_scale/shift */
   float slope;
   float out_scale;         /* epilogue: y = (conv + bias + res) * out_scale                        */
+  int d2s_h, d2s_w;        /* > 0 (vca_conv_fwd_bf16 only): depth-to-space epilogue.  The Cout columns
+                              are 4 groups (ry, rx) of Cout/4 channels; column (ry, rx, c) of output
+                              pixel (oy, ox) is stored as channel c of pixel (2*oy+ry, 2*ox+rx) of a
+                              [N][d2s_h][d2s_w][Cout/4] tensor (pixels outside it are dropped; res has
+                              that shape too).  With the mode-2 weight pack this is the input gradient
+                              of a 3x3 stride-2 convolution (resnet.py:5-9) without multiplying the
+                              zeros of a dilated output gradient.                                   */
 } vca_conv_desc;
 
 /* y = conv(prologue(x), w) + bias (+ res), * out_scale.
@@ -104,6 +111,9 @@ int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const 
  * gradient of the convolution's bias, are ADDED (fp32, from the output-gradient tiles the kernel stages anyway). */
 int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, const float* gy, const float* in_scale,
                         const float* in_shift, const float* in_alpha, float* dwpack, float* bias_grad, void* stream);
+/* mode 2 (taps = 9): the input gradient of a 3x3 / stride 2 / padding 1 convolution in sub-pixel form: 4 taps
+ * (dy, dx) over the output gradient, N = 4*Cin columns (ry, rx, ci), K = Cout; for a descriptor with KH = KW = 2,
+ * stride 1, padding 0, OH x OW = the output gradient's size and d2s_h x d2s_w = the input's. */
 long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps);
 int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream);
 /* vca_pack_weight_bf16 for many weights in one launch (all packed copies of one network after its optimizer step;

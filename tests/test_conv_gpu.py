@@ -25,6 +25,7 @@ CASES = [
     (1, 6, 5, 80, 321, 1, 1, 0, 0),        # odd Cout
     (1, 7, 6, 321, 16, 1, 1, 0, 0),        # odd Cin
     (2, 6, 6, 256, 256, 3, 1, 1, 0),
+    (2, 13, 9, 24, 40, 3, 2, 1, 0),        # stride 2 on odd map sizes (sub-pixel input gradient drops the last row/column)
 ]
 
 
@@ -195,3 +196,34 @@ def test_conv2d_gradients_into_sinks(case, prec, tol):
     assert rel_err(bd.grad - b0.cuda(), br.grad) < max(tol / 50, 2e-5)      # fp32 sums whatever the product precision
     assert rel_err(wd.grad - w0.cuda(), wr.grad) < tol
     assert rel_err(xd.grad.permute(0, 3, 1, 2), xr.grad) < tol
+
+
+@gpu
+@pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('mixed', 1.5e-2)])
+@pytest.mark.parametrize('case', [(3, 12, 12, 64, 128), (2, 13, 9, 24, 40), (5, 7, 16, 136, 72), (70, 6, 6, 256, 512)])
+def test_stride2_input_gradient_subpixel_form(case, prec, tol):
+    """Input gradient of a 3x3 / stride 2 / padding 1 convolution (resnet.py:5-9) as a 2x2 convolution of the
+    undilated output gradient with a depth-to-space epilogue, against torch and against the zero-dilated form,
+    with and without a tensor added in the epilogue."""
+    from vcagan_amd import ops
+    ops.set_precision(prec)
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    cfg = ops.ConvCfg(w.shape, (N, H, W, Cin), 2, (1, 1), 0)
+    assert cfg.subpixel_dgrad()
+    gy = torch.randn(cfg.yshape, generator=g)
+    res = torch.randn(N, H, W, Cin, generator=g)
+    want = torch.nn.grad.conv2d_input((N, Cin, H, W), w, gy.permute(0, 3, 1, 2), 2, 1).permute(0, 2, 3, 1)
+    wd, gyd, resd = w.cuda(), gy.cuda(), res.cuda()
+    got = ops._conv_dgrad_raw(gyd, wd, cfg)
+    got_res = ops._conv_dgrad_raw(gyd, wd, cfg, res=resd)
+    assert rel_err(got, want) < tol
+    assert rel_err(got_res, want + res) < tol
+    ops.SUBPIXEL_DGRAD = False
+    try:
+        assert not cfg.subpixel_dgrad()
+        dilated = ops._conv_dgrad_raw(gyd, wd, cfg)
+    finally:
+        ops.SUBPIXEL_DGRAD = True
+    assert rel_err(got, dilated.cpu()) < (1e-5 if prec == 'bf16x3' else 1e-2)

@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ('N', 'D', 'Hin', 'Win', 'Cin', 'OD', 'OH', 'OW', 'Cout', 'KD', 'KH', 'KW', 'stride', 'pad_h',
-                 'pad_w', 'pad_d', 'dil', 'ups', 'act')] + [('slope', ctypes.c_float), ('out_scale', ctypes.c_float)]
+                 'pad_w', 'pad_d', 'dil', 'ups', 'act')] + [('slope', ctypes.c_float), ('out_scale', ctypes.c_float),
+                                                               ('d2s_h', ctypes.c_int), ('d2s_w', ctypes.c_int)]
 
 
 class LossHead(ctypes.Structure):

@@ -278,11 +278,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   }
 
   // ---- epilogue: D[row][col]: col = lane&15, row = 4*(lane>>4) + r
+  // d2s_h > 0: the GEMM's Cout columns are 4 groups (ry, rx) of Cout/4 channels and column (ry, rx, c) of output
+  // pixel (oy, ox) is element c of pixel (2*oy + ry, 2*ox + rx) of a [N][d2s_h][d2s_w][Cout/4] tensor
+  const int cq = d.Cout >> 2;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * WTN + j * 16 + lr;
     const bool nv = n < d.Cout;
     const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+    const int grp = d.d2s_h ? n / cq : 0;
+    const int nc = n - grp * cq, ry = grp >> 1, rx = grp & 1;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -299,7 +304,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
           s1 += v;
           s2 += v * v;
           v += b;
-          const size_t o = ((size_t)(nn * d.OH + oy) * d.OW + ox) * d.Cout + n;
+          size_t o = ((size_t)(nn * d.OH + oy) * d.OW + ox) * d.Cout + n;
+          if (d.d2s_h) {
+            const int py = 2 * oy + ry, px = 2 * ox + rx;
+            if (py >= d.d2s_h || px >= d.d2s_w) continue;
+            o = ((size_t)(nn * d.d2s_h + py) * d.d2s_w + px) * cq + nc;
+          }
           if (a.ksplit > 1) {
             atomicAdd(a.y + o, v);
           } else {
@@ -875,6 +885,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
 // ------------------------------------------------------------------------------------------------
 // weight packing: fp32 [Cout][Cin][taps] -> bf16 [tap][chunk][npad][hi 32 | lo 32]
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float s2_weight(const float* __restrict__ src, int Cin, int tap, int n, int co);
+
 __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, int N, int K, int npad, int nchunk,
                                         const float* __restrict__ src, __bf16* __restrict__ dst) {
   const size_t total = (size_t)taps * nchunk * npad * 32;
@@ -889,13 +901,30 @@ __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, i
   float v = 0.f;
   if (n < N && k < K) {
     if (mode == 0) v = src[((size_t)n * Cin + k) * taps + tap];                    // N = Cout, K = Cin
-    else v = src[((size_t)k * Cin + n) * taps + (taps - 1 - tap)];                 // N = Cin,  K = Cout
+    else if (mode == 1) v = src[((size_t)k * Cin + n) * taps + (taps - 1 - tap)];  // N = Cin,  K = Cout
+    else v = s2_weight(src, Cin, tap, n, k);
   }
   const __bf16 h = (__bf16)v;
   const __bf16 l = (__bf16)(v - (float)h);
   const size_t row = ((size_t)(tap * nchunk + chunk) * npad + n) * 64;
   dst[row + j] = h;
   dst[row + 32 + j] = l;
+}
+
+// Mode 2 (input gradient of a 3x3, stride-2, padding-1 convolution in sub-pixel form): the gradient of input pixel
+// (2a + ry, 2b + rx) only involves the filter taps of matching parity, gx[2a+r] = sum over taps k = (r+1)%2 + 2m of
+// w[k] * gy[a + (r+1)/2 - m], so the four parities are four convolutions of the UNdilated output gradient over a
+// 2 x 2 window (offsets dy, dx in {0, 1}), run as one convolution with 4*Cin output columns (ry, rx, ci) whose
+// epilogue interleaves them: 16 multiply-adds per output-gradient pixel instead of the 36 of the zero-dilated form.
+// dst taps: (dy, dx); N = 4*Cin; K = Cout.
+__device__ __forceinline__ float s2_weight(const float* __restrict__ src, int Cin, int tap, int n, int co) {
+  const int grp = n / Cin, ci = n - grp * Cin;
+  const int ry = grp >> 1, rx = grp & 1, dy = tap >> 1, dx = tap & 1;
+  // r = 0: offset 0 <- tap 1;  r = 1: offset 1 <- tap 0, offset 0 <- tap 2
+  const int ky = ry ? (dy ? 0 : 2) : (dy ? -1 : 1);
+  const int kx = rx ? (dx ? 0 : 2) : (dx ? -1 : 1);
+  if (ky < 0 || kx < 0) return 0.f;
+  return src[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
 }
 
 // Same packing for filters of at most 32 taps with coalesced traffic on both sides: a workgroup stages the
@@ -907,6 +936,26 @@ __device__ __forceinline__ void pack_tile_bf16(int mode, int Cin, int taps, int 
   const int k0 = chunk * 32;
   const int tid = threadIdx.x;
   const int per = 32 * taps;
+  if (mode == 2) {   // 4 destination taps, gathered straight from the source (small filters, a few KB per tile)
+    for (int i = tid; i < 4 * 32; i += 256) {
+      const int jq = i & 3, nl = (i >> 2) & 7, t = i >> 5;
+      const int n = n0 + nl;
+      if (n < npad) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + jq * 8 + u;
+          v[u] = (n < N && k < K) ? s2_weight(src, Cin, t, n, k) : 0.f;
+        }
+        uint4 h, l;
+        split8(v, h, l);
+        unsigned char* row = reinterpret_cast<unsigned char*>(dst) + ((size_t)(t * nchunk + chunk) * npad + n) * 128;
+        *reinterpret_cast<uint4*>(row + jq * 16) = h;
+        *reinterpret_cast<uint4*>(row + 64 + jq * 16) = l;
+      }
+    }
+    return;
+  }
   if (mode == 0) {
     const int rmax = min(K - k0, 32) * taps;          // entries of this slice that exist in the source
     for (int r = tid; r < per; r += 256) {
@@ -971,7 +1020,7 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_batch_kernel(const vca_p
   }
   const vca_pack_desc d = table[lo];
   const int local = tile - d.tile_begin;
-  const int K = d.mode == 0 ? d.Cin : d.Cout, N = d.mode == 0 ? d.Cout : d.Cin;
+  const int K = d.mode == 0 ? d.Cin : d.Cout, N = d.mode == 0 ? d.Cout : (d.mode == 1 ? d.Cin : 4 * d.Cin);
   const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
   if (local >= nchunk * (npad / 8)) return;
   pack_tile_bf16(d.mode, d.Cin, d.taps, N, K, npad, nchunk, d.src, reinterpret_cast<__bf16*>(d.dst), local % nchunk,
@@ -1044,7 +1093,8 @@ int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
     if (ks > a.nchunk) ks = a.nchunk;       // down to one 32-channel slice per workgroup
     if (ks > 1) {
       a.ksplit = ks;
-      vca_zero_async(a.y, (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout, s);
+      vca_zero_async(a.y, a.d.d2s_h ? (size_t)a.d.N * a.d.d2s_h * a.d.d2s_w * (a.d.Cout / 4)
+                                    : (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout, s);
     }
   }
   hipLaunchKernelGGL(kern, dim3(gx, gy, a.ksplit), dim3(256), lds, s, a);
@@ -1145,14 +1195,15 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
 }
 
 extern "C" long long vca_pack_weight_bf16_bytes(int mode, int Cout, int Cin, int taps) {
-  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+  const int N = mode == 0 ? Cout : (mode == 1 ? Cin : 4 * Cin), K = mode == 0 ? Cin : Cout;
   const long long npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
-  return (long long)taps * nchunk * npad * 128;
+  return (long long)(mode == 2 ? 4 : taps) * nchunk * npad * 128;
 }
 
 extern "C" int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const float* src, void* dst, void* stream) {
-  VCA_CHECK_ARG((mode == 0 || mode == 1) && Cout > 0 && Cin > 0 && taps > 0 && src && dst);
-  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+  VCA_CHECK_ARG(mode >= 0 && mode <= 2 && Cout > 0 && Cin > 0 && taps > 0 && src && dst);
+  VCA_CHECK_ARG(mode != 2 || taps == 9);
+  const int N = mode == 0 ? Cout : (mode == 1 ? Cin : 4 * Cin), K = mode == 0 ? Cin : Cout;
   const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
   if (taps <= 32) {
     const dim3 grid(nchunk, npad / 8);
@@ -1185,6 +1236,8 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   VCA_CHECK_ARG(d->act != VCA_ACT_PRELU || in_alpha);
   VCA_CHECK_ARG((long long)d->N * d->OH * d->OW < (1ll << 31));
   VCA_CHECK_ARG(d->KH * d->KW <= MAXPOS);
+  VCA_CHECK_ARG(d->d2s_h >= 0 && d->d2s_w >= 0 && (d->d2s_h > 0) == (d->d2s_w > 0));
+  VCA_CHECK_ARG(d->d2s_h == 0 || (d->Cout % 4 == 0 && !stats && !bias && d->d2s_h <= 2 * d->OH && d->d2s_w <= 2 * d->OW));
   HArgs a;
   a.d = *d;
   a.x = x; a.w = reinterpret_cast<const unsigned char*>(wpack); a.bias = bias;

@@ -103,7 +103,8 @@ def get_precision():
 
 def _pack(w, mode):
     """mode 0: forward layout [taps][Cin][Cout4]; mode 1: input-gradient layout [taps][Cout][Cin4];
-    modes 10 / 11: the same two roles in the split-bf16 layout [tap][chunk][n][hi 32 | lo 32]."""
+    modes 10 / 11: the same two roles in the split-bf16 layout [tap][chunk][n][hi 32 | lo 32]; mode 12: the
+    sub-pixel input-gradient layout of a 3x3 stride-2 convolution (4 taps, 4*Cin columns)."""
     cout, cin, taps = _wdims(w)
     cacheable = isinstance(w, torch.nn.Parameter)
     if cacheable:
@@ -179,7 +180,18 @@ class ConvCfg:
                         1, self.kh, self.kw, 1, self.kh - 1 - self.pad_h, self.kw - 1 - self.pad_w, 0,
                         self.stride, 0, 0, 0.0, 1.0)
 
+    def subpixel_dgrad(self):
+        """True for the 3x3 / stride 2 / padding 1 convolutions (resnet.py:5-9 stage entries), whose input gradient
+        runs as a 2x2 convolution of the undilated output gradient with a depth-to-space epilogue."""
+        return (SUBPIXEL_DGRAD and self.kd == 1 and self.stride == 2 and self.kh == self.kw == 3 and
+                self.pad_h == self.pad_w == 1 and not self.ups and self.cout > 1)
 
+    def subpixel_dgrad_desc(self):
+        return ConvDesc(self.n, 1, self.oh, self.ow, self.cout, 1, self.oh, self.ow, 4 * self.cin,
+                        1, 2, 2, 1, 0, 0, 0, 1, 0, 0, 0.0, 1.0, self.hin, self.win)
+
+
+SUBPIXEL_DGRAD = True   # False: stride-2 input gradients over the zero-dilated output gradient (the general form)
 _exact_bwd = [False]   # True while a backward runs under create_graph (its results feed a loss value: R1 penalty)
 
 
@@ -225,7 +237,10 @@ def _conv_dgrad_raw(gy, w, cfg, res=None):
     ns = _nsplit(True)
     fuse = res is not None and not cfg.ups
     r = _c(res) if fuse else None
-    if ns and cfg.cout > 1:
+    if ns and cfg.subpixel_dgrad():
+        check(_lib.lib().vca_conv_fwd_bf16(cfg.subpixel_dgrad_desc(), ns, ptr(gy), _pack(w, 12).data_ptr(), None, None,
+                                           None, None, ptr(r), ptr(gx), None, stream()), 'conv_dgrad_bf16_subpixel')
+    elif ns and cfg.cout > 1:
         check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, ptr(r),
                                            ptr(gx), None, stream()), 'conv_dgrad_bf16')
     else:
@@ -1634,7 +1649,7 @@ class _RepackPlan:
             cout, cin, taps = _wdims(p) if p.dim() >= 2 else (0, 0, 0)
             if taps < 1 or taps > 32 or p.dim() == 5:
                 continue
-            for mode in (10, 11):
+            for mode in (10, 11, 12):
                 if mode in ent[1]:
                     out.append((p, mode - 10, ent[1][mode][1], cout, cin, taps, ent))
         return out
@@ -1651,7 +1666,7 @@ class _RepackPlan:
             rec = np.zeros((len(ents), 5), dtype=np.int64)      # 40-byte records: src, dst, (mode,Cout), (Cin,taps), (tile_begin,0)
             tiles, mt = 0, 0
             for i, (p, m, t, cout, cin, taps, _) in enumerate(ents):
-                n, k = (cout, cin) if m == 0 else (cin, cout)
+                n, k = (cout, cin) if m == 0 else ((cin, cout) if m == 1 else (4 * cin, cout))
                 rec[i, 0], rec[i, 1] = p.data_ptr(), t.data_ptr()
                 rec[i, 2] = m | (cout << 32)
                 rec[i, 3] = cin | (taps << 32)
