@@ -192,6 +192,15 @@ int vca_affine_act_pool3_fwd_f32(int N, int H, int W, int C, const float* x, con
  * mode 0: average large->small; 1: its adjoint small->large; 2: block sum large->small; 3: nearest upsample. */
 int vca_pool2_f32(int mode, int N, int Hs, int Ws, int Hl, int Wl, int C, const float* x, float* y, void* stream);
 
+/* Entry of a down-sampling discriminator block (generator.py:71-83: the block input goes through LeakyReLU into the
+ * residual branch and through F.avg_pool2d(x, 2) into the shortcut) in one pass: y_act = LeakyReLU(x, slope) on
+ * [N][H][W][C], y_pool = 2x2 average on [N][H/2][W/2][C] (floor).  Backward in one pass as well:
+ * gx = g_act * LeakyReLU'(x) + g_pool[h/2][w/2] / 4 (either gradient may be NULL). */
+int vca_leaky_pool2_fwd_f32(int N, int H, int W, int C, float slope, const float* x, float* y_act, float* y_pool,
+                            void* stream);
+int vca_leaky_pool2_bwd_f32(int N, int H, int W, int C, float slope, const float* g_act, const float* g_pool,
+                            const float* x, float* gx, void* stream);
+
 /* MaxPool (3x3, stride 2, pad 1) of visual_front.py:14 (per frame), forward (+argmax tap) and backward. */
 int vca_maxpool3s2_fwd_f32(int N, int H, int W, int C, const float* x, float* y, unsigned char* idx, void* stream);
 int vca_maxpool3s2_bwd_f32(int N, int H, int W, int C, const float* gy, const unsigned char* idx, float* gx,

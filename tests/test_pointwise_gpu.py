@@ -275,3 +275,37 @@ def test_bn_act_maxpool3_fused_equals_separate_ops(train):
     for u, v in ((bn.weight, bn2.weight), (bn.bias, bn2.bias), (pr.weight, pr2.weight)):
         assert torch.allclose(u.grad, v.grad, atol=1e-4, rtol=1e-5), float((u.grad - v.grad).abs().max())
     assert torch.allclose(bn.running_mean, bn2.running_mean) and torch.allclose(bn.running_var, bn2.running_var)
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(2, 8, 10, 32), (3, 9, 7, 64), (2, 37, 10, 256), (1, 2, 3, 4)])
+def test_leaky_avgpool2_fused(shape):
+    """LeakyReLU + 2x2 average of one map in one pass (the entry of a down-sampling discriminator block,
+    generator.py:71-83) against torch: both outputs, the joined input gradient, and the gradient of that gradient
+    (the R1 penalty differentiates the blocks' backward pass), on even and odd map sizes."""
+    import torch.nn.functional as F
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    ga, ggx = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    n, h, w, c = shape
+    gp = torch.randn(n, h // 2, w // 2, c, generator=g)
+
+    def run(fn, dev):
+        xx = x.to(dev).requires_grad_(True)
+        ya, yp = fn(xx)
+        a, p = ga.to(dev).requires_grad_(True), gp.to(dev).requires_grad_(True)
+        gx, = torch.autograd.grad([ya, yp], xx, [a, p], create_graph=True)
+        da, dp = torch.autograd.grad(gx, [a, p], ggx.to(dev))
+        gx_a, = torch.autograd.grad(ya, xx, a.detach(), retain_graph=True)       # one branch only
+        gx_p, = torch.autograd.grad(yp, xx, p.detach())
+        return [t.detach().cpu() for t in (ya, yp, gx, da, dp, gx_a, gx_p)]
+
+    def ref(xx):
+        return F.leaky_relu(xx, 0.2), F.avg_pool2d(xx.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+
+    want = run(ref, 'cpu')
+    got = run(ops.leaky_avgpool2, 'cuda')
+    for name, a, b in zip(('act', 'pool', 'gx', 'd/dga', 'd/dgp', 'gx(act only)', 'gx(pool only)'), got, want):
+        assert a.shape == b.shape, name
+        assert float((a - b).abs().max()) < 1e-6, name

@@ -331,6 +331,79 @@ __global__ __launch_bounds__(THR) void pool2_kernel(int mode, int N, int Hs, int
   }
 }
 
+// Entry of a down-sampling discriminator block (generator.py:71-83): the block input feeds LeakyReLU (residual branch)
+// and a 2x2 average (shortcut).  One pass over the map writes both; the backward pass is one kernel as well,
+// gx = ga * leaky'(x) + gp[h/2][w/2] / 4, instead of an activation backward, a pooling adjoint and the add that joins
+// them.  One thread per 2x2 block and 4 channels; rows / columns beyond 2*(H/2), 2*(W/2) are not pooled (floor).
+__global__ __launch_bounds__(THR) void leaky_pool2_fwd_kernel(int N, int H, int W, int C, float slope,
+                                                              const float* __restrict__ x, float* __restrict__ ya,
+                                                              float* __restrict__ yp) {
+  const int C4 = C >> 2, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1, Hs = H >> 1, Ws = W >> 1;
+  const size_t total = (size_t)N * Hb * Wb * C4;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int wb = r % Wb; r /= Wb;
+    const int hb = r % Hb;
+    const int n = r / Hb;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int h = 2 * hb + dy, w = 2 * wb + dx;
+        if (h < H && w < W) {
+          const size_t o = (((size_t)n * H + h) * W + w) * C + c;
+          const float4 v = ld4(x + o);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          st4(ya + o, make_float4(v.x > 0.f ? v.x : v.x * slope, v.y > 0.f ? v.y : v.y * slope,
+                                  v.z > 0.f ? v.z : v.z * slope, v.w > 0.f ? v.w : v.w * slope));
+        }
+      }
+    if (hb < Hs && wb < Ws)
+      st4(yp + (((size_t)n * Hs + hb) * Ws + wb) * C + c,
+          make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f));
+  }
+}
+
+__global__ __launch_bounds__(THR) void leaky_pool2_bwd_kernel(int N, int H, int W, int C, float slope,
+                                                              const float* __restrict__ ga,
+                                                              const float* __restrict__ gp,
+                                                              const float* __restrict__ x, float* __restrict__ gx) {
+  const int C4 = C >> 2, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1, Hs = H >> 1, Ws = W >> 1;
+  const size_t total = (size_t)N * Hb * Wb * C4;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int wb = r % Wb; r /= Wb;
+    const int hb = r % Hb;
+    const int n = r / Hb;
+    float4 p = make_float4(0, 0, 0, 0);
+    if (gp && hb < Hs && wb < Ws) {
+      p = ld4(gp + (((size_t)n * Hs + hb) * Ws + wb) * C + c);
+      p.x *= 0.25f; p.y *= 0.25f; p.z *= 0.25f; p.w *= 0.25f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int h = 2 * hb + dy, w = 2 * wb + dx;
+        if (h < H && w < W) {
+          const size_t o = (((size_t)n * H + h) * W + w) * C + c;
+          float4 out = p;
+          if (ga) {
+            const float4 v = ld4(x + o), g = ld4(ga + o);
+            out.x += v.x > 0.f ? g.x : g.x * slope;
+            out.y += v.y > 0.f ? g.y : g.y * slope;
+            out.z += v.z > 0.f ? g.z : g.z * slope;
+            out.w += v.w > 0.f ? g.w : g.w * slope;
+          }
+          st4(gx + o, out);
+        }
+      }
+  }
+}
+
 // 3x3 stride-2 pad-1 max pool, forward (also writes the argmax tap 0..8) and backward (scatter by gather)
 __global__ __launch_bounds__(THR) void maxpool3_fwd_kernel(int N, int H, int W, int OH, int OW, int C,
                                                            const float* __restrict__ x, float* __restrict__ y,
@@ -547,6 +620,22 @@ extern "C" int vca_pool2_f32(int mode, int N, int Hs, int Ws, int Hl, int Wl, in
   const size_t total = (size_t)N * (down ? Hs : Hl) * (down ? Ws : Wl) * (C / 4);
   hipLaunchKernelGGL(pool2_kernel, dim3(grid_for(total)), dim3(THR), 0, (hipStream_t)stream, mode, N, Hs, Ws, Hl, Wl,
                      C, x, y);
+  return vca_launch_status();
+}
+
+extern "C" int vca_leaky_pool2_fwd_f32(int N, int H, int W, int C, float slope, const float* x, float* y_act,
+                                       float* y_pool, void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0 && x && y_act && y_pool);
+  hipLaunchKernelGGL(leaky_pool2_fwd_kernel, dim3(grid_for((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4))),
+                     dim3(THR), 0, (hipStream_t)stream, N, H, W, C, slope, x, y_act, y_pool);
+  return vca_launch_status();
+}
+
+extern "C" int vca_leaky_pool2_bwd_f32(int N, int H, int W, int C, float slope, const float* g_act,
+                                       const float* g_pool, const float* x, float* gx, void* stream) {
+  VCA_CHECK_ARG(N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0 && x && gx && (g_act || g_pool));
+  hipLaunchKernelGGL(leaky_pool2_bwd_kernel, dim3(grid_for((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4))),
+                     dim3(THR), 0, (hipStream_t)stream, N, H, W, C, slope, g_act, g_pool, x, gx);
   return vca_launch_status();
 }
 

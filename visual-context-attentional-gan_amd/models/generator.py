@@ -57,9 +57,9 @@ class ResBlk(nn.Module):
     def forward(self, x):                                     # (B, H, W, C)
         # shortcut (generator.py:71-77: 1x1 convolution, then 2x2 average): both are linear and the convolution is
         # pointwise, so they commute; pooling first runs the convolution on a quarter of the positions
-        s = ops.avgpool2(x) if self.downsample else x
+        a, s = ops.leaky_avgpool2(x) if self.downsample else (ops.leaky(x), x)
         s = _conv(s, self.conv1x1) if self.learned_sc else s
-        r = _conv(ops.leaky(x), self.conv1)
+        r = _conv(a, self.conv1)
         if self.downsample:
             r = ops.avgpool2(r)
         r = _conv(ops.leaky(r), self.conv2)

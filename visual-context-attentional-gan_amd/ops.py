@@ -996,6 +996,62 @@ def avgpool2(x):
     return Pool2Fn.apply(x, 0, (h // 2, w // 2), (h, w))
 
 
+class LeakyPool2Fn(torch.autograd.Function):
+    """(LeakyReLU(x), avg_pool2d(x, 2)) of one map in one pass: the entry of a down-sampling discriminator block
+    (generator.py:71-83).  Its backward is one kernel too (no separate activation backward, pooling adjoint and the
+    add that joins the two branches), and differentiable (the blocks sit on the R1 path)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = _c(x)
+        n, h, w, c = x.shape
+        ya = torch.empty_like(x)
+        yp = torch.empty((n, h // 2, w // 2, c), device=x.device, dtype=torch.float32)
+        check(_lib.lib().vca_leaky_pool2_fwd_f32(n, h, w, c, slope, ptr(x), ptr(ya), ptr(yp), stream()), 'leaky_pool2')
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        ctx.set_materialize_grads(False)
+        return ya, yp
+
+    @staticmethod
+    def backward(ctx, ga, gp):
+        x, = ctx.saved_tensors
+        if ga is None and gp is None:
+            return None, None
+        return LeakyPool2BwdFn.apply(ga, gp, x, ctx.slope), None
+
+
+class LeakyPool2BwdFn(torch.autograd.Function):
+    """gx = ga * LeakyReLU'(x) + avg_pool2d-adjoint(gp): linear in (ga, gp), so its own backward is the forward pair
+    applied to the incoming gradient (with the activation's mask taken from x)."""
+
+    @staticmethod
+    def forward(ctx, ga, gp, x, slope):
+        n, h, w, c = x.shape
+        ga = None if ga is None else _c(ga)
+        gp = None if gp is None else _c(gp)
+        gx = torch.empty_like(x)
+        check(_lib.lib().vca_leaky_pool2_bwd_f32(n, h, w, c, slope, ptr(ga), ptr(gp), ptr(x), ptr(gx), stream()),
+              'leaky_pool2_bwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (slope, ga is not None, gp is not None)
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        x, = ctx.saved_tensors
+        slope, has_a, has_p = ctx.cfg
+        return (ActBwdFn.apply(ggx, x, ACT_LEAKY, slope) if has_a else None,
+                avgpool2(ggx) if has_p else None, None, None)
+
+
+def leaky_avgpool2(x):
+    """(leaky(x), avgpool2(x)) in one pass."""
+    if x.shape[-1] % 4 or x.shape[1] < 2 or x.shape[2] < 2:
+        return leaky(x), avgpool2(x)
+    return LeakyPool2Fn.apply(x, 0.2)
+
+
 class MaxPool3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
