@@ -37,7 +37,8 @@ struct HArgs {
   float* y;
   float* stats;
   int npad, nchunk, ntaps;
-  int NI, TH, TW, HH, HW, NPOS;
+  int NI, TH, TW, HH, HW, NPOS;   // HW: pitch of a halo row in positions, NPOS: pitch of a slot's halo (both may be padded)
+  int HWv;                        // halo positions per row that are actually staged (<= HW)
   int tiles_x, tiles_y, nsub;
   int vecA;
   int ksplit;  // >1: blockIdx.z owns a range of channel slices and adds its partial sums atomically
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
       const int pos = it >> 1;
       const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
       const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      if (hx >= a.HWv || hy >= a.HH) {   // padding of the row / slot pitch: never read by a fragment, never staged
+        hsrc[k] = -2;
+        continue;
+      }
       int n, oy0, ox0;
       bool ok = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
       int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     for (int k = 0; k < NHI; ++k) {
       const int it = tid + k * 256;
       if (it >= npos_total * 2) break;
+      if (hsrc[k] == -2) continue;
       const int pos = it >> 1, half = it & 1;
       float v[16];
 #pragma unroll
@@ -1031,16 +1037,37 @@ struct TileChoice {
   int NI, TH, TW;
 };
 
+// Pitches of the halo image for the 16x16x32 kernel.  Its fragment reads are conflict-free when the 16 rows of a
+// fragment are 16 consecutive halo positions; a fragment that wraps from one patch row to the next (or to the next
+// slot) jumps by pitch - TW (resp. a slot-dependent amount) positions, and the pattern survives exactly when that
+// jump is a multiple of 8 positions.  With `padded` the row pitch is TW + 8k and the slot pitch matches; the padding
+// is never staged and never read.  Measured per layer: -3...-5 % on the 5x5 layers with >= 128 output channels (the
+// split-product launches that sit at the LDS / MFMA limit); a loss wherever the padding shrinks the patch or the
+// number of images per workgroup (small maps: up to 2x), on 3x3 filters (6 padded positions per row for 2 taps of
+// reach) and on the narrow-channel kernels, so only the first group gets it.
+inline void halo_pitch(int TH, int TW, int KH, int KW, int stride, bool padded, int& hw, int& npos) {
+  const int hh = (TH - 1) * stride + KH;
+  hw = (TW - 1) * stride + KW;
+  npos = hh * hw;
+  if (!padded || stride != 1 || KW == 1) return;
+  hw = TW + (KW - 1 + 7) / 8 * 8;
+  npos = hh * hw;
+  // first position of the next slot minus (last position of this slot's tile + 1) must be 0 mod 8
+  const int want = ((TH - 1) * hw + TW) & 7;
+  npos += (want - npos) & 7;
+}
+
 // Patch shape maximising the fraction of the 128 GEMM rows that are real output pixels, subject to the halo
 // fitting in LDS.  Cached per geometry.
 TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Cout, int maxpos = MAXPOS,
-                       double stage_cost = 6.0) {
+                       double stage_cost = 6.0, bool padded = false) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, TileChoice> cache;
   const unsigned long long key = ((unsigned long long)N << 44) ^ ((unsigned long long)OH << 32) ^
                                  ((unsigned long long)OW << 20) ^ (KH << 12) ^ (KW << 4) ^ stride ^
                                  ((unsigned long long)(Cout > 96 ? 3 : (Cout > 32 ? 2 : 1)) << 58) ^
-                                 ((unsigned long long)maxpos << 8) ^ ((unsigned long long)(stage_cost * 4) << 24);
+                                 ((unsigned long long)maxpos << 8) ^ ((unsigned long long)(stage_cost * 4) << 24) ^
+                                 ((unsigned long long)padded << 63);
   {
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find(key);
@@ -1054,11 +1081,13 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Co
   for (int th = 1; th <= OH && th <= BM; ++th) {
     for (int tw = 1; tw <= OW && th * tw <= BM; ++tw) {
       const int hh = (th - 1) * stride + KH, hw = (tw - 1) * stride + KW;
-      if (hh * hw > maxpos) continue;
+      int slot = hh * hw, pitch = hw;
+      halo_pitch(th, tw, KH, KW, stride, padded, pitch, slot);
+      if (slot > maxpos) continue;
       const long long nsub = (long long)N * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
       int ni = BM / (th * tw);
       if (ni > nsub) ni = (int)nsub;
-      while (ni > 1 && ni * hh * hw > maxpos) --ni;
+      while (ni > 1 && ni * slot > maxpos) --ni;
       const long long groups = (nsub + ni - 1) / ni;
       double cost = (double)groups * (mfma + stage_cost * ni * hh * hw);
       cost *= 1.0 + 0.02 / tw;   // tie-break: wider patches (longer contiguous runs, fewer LDS bank conflicts)
@@ -1245,11 +1274,16 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   a.npad = (d->Cout + 31) / 32 * 32;
   a.nchunk = (d->Cin + 31) / 32;
   a.ntaps = d->KH * d->KW;
-  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
+  TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
+  bool padded = false;
+  if (d->stride == 1 && d->KW >= 5 && d->Cout > 64) {   // see halo_pitch: only where the padding costs no patch area
+    const TileChoice tp = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout, MAXPOS, 6.0, true);
+    padded = tp.NI == t.NI && tp.TH == t.TH && tp.TW == t.TW;
+  }
   a.NI = t.NI; a.TH = t.TH; a.TW = t.TW;
   a.HH = (t.TH - 1) * d->stride + d->KH;
-  a.HW = (t.TW - 1) * d->stride + d->KW;
-  a.NPOS = a.HH * a.HW;
+  a.HWv = (t.TW - 1) * d->stride + d->KW;
+  halo_pitch(t.TH, t.TW, d->KH, d->KW, d->stride, padded, a.HW, a.NPOS);
   a.tiles_x = (d->OW + t.TW - 1) / t.TW;
   a.tiles_y = (d->OH + t.TH - 1) / t.TH;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;

@@ -198,7 +198,9 @@ class GanStep:
             hd.add(ops.HEAD_L1, g, ((2, 1.0 / 3), (0, 50.0 / 3)), y=t, scale=k / g.numel())
         hd.add(ops.HEAD_L1, gs, ((2, 1.0), (0, 50.0)), y=st['spec'])
         out = hd.run(4)
-        self._zero(D_NAMES + ('gen', 'post'))
+        # No gradient buffer needs clearing here: the generator side was cleared at the start of the step and the D
+        # phase's backward stops at the detached generator outputs and at phon_d, so it has added nothing to gen /
+        # post; the discriminators' parameters take no gradient in this phase.
         with ops.direct_param_grad():
             torch.autograd.backward([out, phon], [self._onehot(4, 0, out.device), st['phon_d'].grad])
         for p in d_params:
