@@ -244,6 +244,14 @@ int vca_gru_cell_bwd2_f32(int B, int H, int dout_stride, const float* dout0, con
                           const float* dha1, const float* dhb0, const float* dhb1, const float* save0,
                           const float* save1, const float* hp0, const float* hp1, float* dgi0, float* dgi1,
                           float* dgh0, float* dgh1, float* dhd0, float* dhd1, void* stream);
+/* One forward time step of both directions of a bidirectional GRU layer (nn.GRU, visual_front.py:20,33-34) in one
+ * launch: gh = h_prev . W_hh^T + b_hh on the matrix cores (W packed by vca_pack_weight_bf16 mode 0, [3H][H]) with the
+ * gate arithmetic of vca_gru_cell_fwd2_f32 in the epilogue.  hp0/hp1 NULL = zero initial state.  gi: [B][3H] input
+ * gates of this step; writes h_new [B][H], out (row stride out_stride) and save [B][4H] = (r, z, n, gh_n). */
+int vca_gru_fwd_step_bf16(int nsplit, int B, int H, const float* hp0, const float* hp1, const void* w0, const void* w1,
+                          const float* bhh0, const float* bhh1, const float* gi0, const float* gi1, float* hn0,
+                          float* hn1, float* out0, float* out1, int out_stride, float* save0, float* save1,
+                          void* stream);
 /* One step of the GRU backward recurrence (visual_front.py:20 backward) for both directions in one launch: the
  * recurrent product dh = d_gh(previous step) . W_hh (w_i: vca_pack_weight_bf16 mode 1 of the (3H, H) weight) with
  * the gate arithmetic of vca_gru_cell_bwd2_f32 applied in its epilogue (dh_a is the product itself). */

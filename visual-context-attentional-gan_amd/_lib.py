@@ -87,6 +87,7 @@ _SIGS = {
     'vca_gru_cell_bwd_f32': ([_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_gru_cell_fwd2_f32': ([_I, _I, _I] + [_P] * 13, _I),
     'vca_gru_cell_bwd2_f32': ([_I, _I, _I] + [_P] * 17, _I),
+    'vca_gru_fwd_step_bf16': ([_I, _I, _I] + [_P] * 12 + [_I, _P, _P, _P], _I),
     'vca_gru_bwd_step_bf16': ([_I, _I, _I, _P, _P, _P, _P, _I] + [_P] * 15, _I),
     'vca_skinny_gemm_bf16': ([_I, _I, _I, _I, _I] + [_P] * 9, _I),
     'vca_softplus_sum_f32': ([_I, _P, _F, _F, _P, _P], _I),

@@ -278,7 +278,120 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
   }
 }
 
+// One forward time step of both directions of a GRU layer in one launch: the recurrent product gh = h_prev . W_hh^T
+// + b_hh and the gate arithmetic of gru_cell_fwd2_kernel in its epilogue.  A workgroup owns 8 hidden units of up to 32
+// sequences and computes the three gate columns of those units (24 of the 32 columns of one MFMA tile: rows
+// g*H + unit of the packed weight, picked per lane), so the cell needs nothing from another workgroup; the NW waves
+// split the reduction as in skinny_gemm_kernel.  2*H/8 workgroups of ~50 KB of weights each keep the dependent chain
+// (75 steps per layer) short.
+struct GruFwdArgs {
+  const float* hp[2]; const unsigned char* w[2]; const float* bhh[2]; const float* gi[2];
+  float* h_new[2]; float* out[2]; float* save[2];
+  int B, H, npad, nsplit, out_stride;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gru_fwd_step_kernel(GruFwdArgs a) {
+  __shared__ float red[NW][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int z = blockIdx.z, u0 = blockIdx.x * 8, m0 = blockIdx.y * 32;
+  const int H = a.H;
+  const float* x = a.hp[z];
+  const unsigned char* w = a.w[z];
+  const int nks = (H + 15) / 16;
+  const int per = (nks + NW - 1) / NW;
+  const int ks_beg = wave * per, ks_end = min(nks, ks_beg + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int row = m0 + lr;
+  const bool rv = row < a.B;
+  const int gate = lr >> 3, unit = u0 + (lr & 7);
+  const int brow = (gate < 3 && unit < H) ? gate * H + unit : 0;   // columns 24..31 are never read back
+  constexpr int CH = 8;
+  if (x) {
+    for (int base = ks_beg; base < ks_end; base += CH) {
+      float4 ap[CH], aq[CH];
+      bf16x8 bh[CH], bl[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int ks = base + j;
+        const int k0 = ks * 16 + lh * 8;
+        ap[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        aq[j] = ap[j];
+        const bool kv = ks < ks_end;
+        if (rv && kv) {
+          const float* src = x + (size_t)row * H + k0;
+          ap[j] = *reinterpret_cast<const float4*>(src);
+          aq[j] = *reinterpret_cast<const float4*>(src + 4);
+        }
+        const int ksc = kv ? ks : ks_beg;
+        const unsigned char* wp = w + ((size_t)(ksc >> 1) * a.npad + brow) * 128 + ((ksc & 1) * 16 + lh * 8) * 2;
+        bh[j] = *reinterpret_cast<const bf16x8*>(wp);
+        if (a.nsplit == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wp + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float v[8] = {ap[j].x, ap[j].y, ap[j].z, ap[j].w, aq[j].x, aq[j].y, aq[j].z, aq[j].w};
+        bf16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ah[e] = (__bf16)v[e];
+          al[e] = (__bf16)(v[e] - (float)ah[e]);
+        }
+        if (a.nsplit == 3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < 32 * 8; i += 64 * NW) {
+    const int m = i >> 3, u = i & 7;
+    const int b = m0 + m, j = u0 + u;
+    if (b >= a.B || j >= H) continue;
+    float gh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      float t = a.bhh[z] ? a.bhh[z][g * H + j] : 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) t += red[w8][m][g * 8 + u];
+      gh[g] = t;
+    }
+    const float* gib = a.gi[z] + (size_t)b * 3 * H;
+    const float r = sigmoidf_(gib[j] + gh[0]);
+    const float zg = sigmoidf_(gib[H + j] + gh[1]);
+    const float n = tanhf(gib[2 * H + j] + r * gh[2]);
+    const float hp = x ? x[(size_t)b * H + j] : 0.f;
+    const float h = (1.f - zg) * n + zg * hp;
+    a.h_new[z][(size_t)b * H + j] = h;
+    a.out[z][(size_t)b * a.out_stride + j] = h;
+    float* sv = a.save[z] + (size_t)b * 4 * H;
+    sv[j] = r; sv[H + j] = zg; sv[2 * H + j] = n; sv[3 * H + j] = gh[2];
+  }
+}
+
 }  // namespace
+
+extern "C" int vca_gru_fwd_step_bf16(int nsplit, int B, int H, const float* hp0, const float* hp1, const void* w0,
+                                     const void* w1, const float* bhh0, const float* bhh1, const float* gi0,
+                                     const float* gi1, float* hn0, float* hn1, float* out0, float* out1, int out_stride,
+                                     float* save0, float* save1, void* stream) {
+  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && H > 0 && (H % 8) == 0 && w0 && w1 && gi0 && gi1);
+  VCA_CHECK_ARG(hn0 && hn1 && out0 && out1 && save0 && save1 && out_stride >= H && (hp0 == nullptr) == (hp1 == nullptr));
+  GruFwdArgs a;
+  a.hp[0] = hp0; a.hp[1] = hp1;
+  a.w[0] = reinterpret_cast<const unsigned char*>(w0); a.w[1] = reinterpret_cast<const unsigned char*>(w1);
+  a.bhh[0] = bhh0; a.bhh[1] = bhh1; a.gi[0] = gi0; a.gi[1] = gi1;
+  a.h_new[0] = hn0; a.h_new[1] = hn1; a.out[0] = out0; a.out[1] = out1; a.save[0] = save0; a.save[1] = save1;
+  a.B = B; a.H = H; a.npad = (3 * H + 31) / 32 * 32; a.nsplit = nsplit; a.out_stride = out_stride;
+  hipLaunchKernelGGL((gru_fwd_step_kernel<4>), dim3(H / 8, (B + 31) / 32, 2), dim3(256), 0, (hipStream_t)stream, a);
+  return vca_launch_status();
+}
 
 extern "C" int vca_skinny_gemm_bf16(int nsplit, int nprob, int M, int N, int K, const float* x0, const float* x1,
                                     const void* w0, const void* w1, const float* b0, const float* b1, float* y0,

@@ -1490,11 +1490,22 @@ class GruLayerFn(torch.autograd.Function):
         save = [torch.empty((T, B, 4 * H), device=dev, dtype=torch.float32) for _ in range(2)]
         h0 = torch.zeros((B, H), device=dev, dtype=torch.float32)
         w_hh, b_hh = [wts[1], wts[5]], [wts[3], wts[7]]
+        ns = _nsplit()
         for s in range(T):
             ts = (s, T - 1 - s)
+            t0, t1 = ts
+            if ns and H % 8 == 0:
+                # recurrent product and gate arithmetic of the step in one launch for both directions
+                packs = [_pack(w, 10) for w in w_hh]
+                hp = [None, None] if s == 0 else [hbuf[0][s - 1], hbuf[1][T - s]]
+                check(L.vca_gru_fwd_step_bf16(ns, B, H, ptr(hp[0]), ptr(hp[1]), packs[0].data_ptr(),
+                                              packs[1].data_ptr(), ptr(b_hh[0].detach()), ptr(b_hh[1].detach()),
+                                              ptr(gi[0][t0]), ptr(gi[1][t1]), ptr(hbuf[0][t0]), ptr(hbuf[1][t1]),
+                                              out[t0].data_ptr(), out[t1].data_ptr() + 4 * H, 2 * H,
+                                              ptr(save[0][t0]), ptr(save[1][t1]), stream()), 'gru_fwd_step')
+                continue
             hp = [h0 if s == 0 else hbuf[0][s - 1], h0 if s == 0 else hbuf[1][T - s]]
             gh = _rec_gemm(hp, w_hh, b_hh, 0)
-            t0, t1 = ts
             check(L.vca_gru_cell_fwd2_f32(B, H, 2 * H, ptr(gi[0][t0]), ptr(gi[1][t1]), ptr(gh[0]), ptr(gh[1]),
                                           ptr(hp[0]), ptr(hp[1]), ptr(hbuf[0][t0]), ptr(hbuf[1][t1]),
                                           out[t0].data_ptr(), out[t1].data_ptr() + 4 * H, ptr(save[0][t0]),
