@@ -179,11 +179,14 @@ struct SkinnyArgs {
   int dout_stride;
 };
 
-template <bool EP, int NW>
+// NCOL: output columns per workgroup (32, or 16 = half of the MFMA tile left unused: twice the workgroups, half the
+// weight bytes through each CU, for the launches whose duration is a dependent chain of memory round trips).
+template <bool EP, int NW, int NCOL = 32>
 __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
-  __shared__ float red[NW][32][33];   // NW waves split the reduction (8 for the deep K = 3H of the backward step)
+  __shared__ float red[NW][32][NCOL + 1];   // NW waves split the reduction (8 or 12 for the deep K = 3H of the backward step)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  const int z = blockIdx.z, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int z = blockIdx.z, n0 = blockIdx.x * NCOL, m0 = blockIdx.y * 32;
+  const int brow = min(n0 + (lr < NCOL ? lr : 0), a.npad - 1);
   const float* x = a.x[z];
   const unsigned char* w = a.w[z];
   const int nks = (a.K + 15) / 16;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
       }
       // weight row n0+lr of slice ks>>1: 128 B = [hi 32 | lo 32]; this lane's 8 values start at (ks&1)*16 + lh*8
       const int ksc = kv ? ks : ks_beg;        // past the end: any valid address, the A operand is zero
-      const unsigned char* wp = w + ((size_t)(ksc >> 1) * a.npad + n0 + lr) * 128 + ((ksc & 1) * 16 + lh * 8) * 2;
+      const unsigned char* wp = w + ((size_t)(ksc >> 1) * a.npad + brow) * 128 + ((ksc & 1) * 16 + lh * 8) * 2;
       bh[j] = *reinterpret_cast<const bf16x8*>(wp);
       if (a.nsplit == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wp + 64);
     }
@@ -244,11 +247,13 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc, 0, 0, 0);
     }
   }
+  if (lr < NCOL) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  }
   __syncthreads();
-  for (int i = tid; i < 32 * 32; i += 64 * NW) {
-    const int r = i >> 5, c = i & 31;
+  for (int i = tid; i < 32 * NCOL; i += 64 * NW) {
+    const int r = i / NCOL, c = i - r * NCOL;
     const int m = m0 + r, n = n0 + c;
     if (m < a.M && n < a.N) {
       float s = 0.f;
@@ -429,7 +434,12 @@ extern "C" int vca_gru_bwd_step_bf16(int nsplit, int B, int H, const float* dgh_
   a.dout[0] = dout0; a.dout[1] = dout1; a.dh_b[0] = dhb0; a.dh_b[1] = dhb1; a.save[0] = save0; a.save[1] = save1;
   a.h_prev[0] = hp0; a.h_prev[1] = hp1; a.d_gi[0] = dgi0; a.d_gi[1] = dgi1; a.d_gh[0] = dgh0; a.d_gh[1] = dgh1;
   a.dh_direct[0] = dhd0; a.dh_direct[1] = dhd1; a.dout_stride = dout_stride;
-  hipLaunchKernelGGL((skinny_gemm_kernel<true, 8>), dim3((H + 31) / 32, (B + 31) / 32, 2), dim3(512), 0,
-                     (hipStream_t)stream, a);
+  // K = 3H: with 12 waves a wave's share of a 1536-deep reduction is one 8-step chunk, i.e. one round of loads
+  if (3 * H <= 12 * 8 * 16 && 3 * H > 8 * 8 * 16)
+    hipLaunchKernelGGL((skinny_gemm_kernel<true, 12, 16>), dim3((H + 15) / 16, (B + 31) / 32, 2), dim3(768), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((skinny_gemm_kernel<true, 8>), dim3((H + 31) / 32, (B + 31) / 32, 2), dim3(512), 0,
+                       (hipStream_t)stream, a);
   return vca_launch_status();
 }
