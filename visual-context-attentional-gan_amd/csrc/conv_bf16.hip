@@ -711,18 +711,59 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
   const unsigned char* my_gh = gy_hi + coh * BM * 64;
   const unsigned char* my_gl = gy_lo + coh * BM * 64;
 
+  // Staging plan, the same for every patch (integer divisions are the expensive part of staging: done per patch and
+  // item they cost more VALU time than the patch's MFMAs): slot, halo row and column of each of this thread's halo
+  // items, slot and pixel of its output-gradient items, packed as slot | a << 8 | b << 20.  Only the slots' image and
+  // origin change from patch to patch; the first NI threads work them out once per patch (slot_info).
+  int (*slot_info)[4] = reinterpret_cast<int (*)[4]>(smem + a.slot_off);   // [BM]: n, oy0, ox0, valid
+  // (Single product only: the split-product variant has no registers left for the plan - it spilled 15 and lost 1.5 %
+  // of a step - and recomputes the coordinates.)
+  constexpr int NHQ = 3;   // up to 192 positions x 4 quarter slices over 256 threads
+  constexpr bool PLAN = NSPLIT == 1;
+  int plan_h[PLAN ? NHQ : 1], plan_g[PLAN ? 4 : 1];
+#pragma unroll
+  for (int k = 0; k < (PLAN ? NHQ : 0); ++k) {
+    const int pos = (tid + k * 256) >> 2;
+    const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
+    const int hy = rp / a.HW, hx = rp - hy * a.HW;
+    plan_h[k] = (tid + k * 256 < npos_total * 4) ? (img | (hy << 8) | (hx << 20)) : -1;
+  }
+#pragma unroll
+  for (int rep = 0; rep < (PLAN ? 4 : 0); ++rep) {
+    const int m = (tid + rep * 256) >> 3;
+    const int img = m / tpix, rem = m - img * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    plan_g[rep] = img < a.NI ? (img | (ty << 8) | (tx << 20)) : -1;
+  }
+
   const int pt_beg = blockIdx.y * a.tiles_per_block;
   const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
   for (int pt = pt_beg; pt < pt_end; ++pt) {
     const int sid0 = pt * a.NI;
-    __syncthreads();
-    // ---- input halo, channels ci_base .. ci_base+63: 4 threads per position, 16 channels each
-    for (int it = tid; it < npos_total * 4; it += 256) {
-      const int pos = it >> 2, qtr = it & 3;
-      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
-      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+    if (tid < a.NI) {
       int n, oy0, ox0;
-      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      const bool sv = slot_origin(sid0 + tid, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      slot_info[tid][0] = n; slot_info[tid][1] = oy0; slot_info[tid][2] = ox0; slot_info[tid][3] = sv;
+    }
+    __syncthreads();   // slot_info visible; the previous patch's fragments have been read
+    // ---- input halo, channels ci_base .. ci_base+63: 4 threads per position, 16 channels each
+#pragma unroll
+    for (int k = 0; k < NHQ; ++k) {
+      const int it = tid + k * 256;
+      if (it >= npos_total * 4) break;
+      asm volatile("" ::: "memory");   // one item at a time in registers (the accumulators of 9 taps leave room for no more)
+      const int pos = it >> 2, qtr = it & 3;
+      int img, hy, hx;
+      if constexpr (PLAN) {
+        img = plan_h[k] & 255; hy = (plan_h[k] >> 8) & 4095; hx = plan_h[k] >> 20;
+      } else {
+        img = pos / a.NPOS;
+        const int rp = pos - img * a.NPOS;
+        hy = rp / a.HW; hx = rp - hy * a.HW;
+      }
+      const int4 si = *reinterpret_cast<const int4*>(slot_info[img]);
+      const int n = si.x, oy0 = si.y, ox0 = si.z;
+      const bool sv = si.w != 0;
       int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
       const bool ok = sv && vy >= 0 && vx >= 0 && vy < He && vx < We;
       vy >>= d.ups;
@@ -774,16 +815,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
     for (int rep = 0; rep < 4; ++rep) {
       const int it = tid + rep * 256;
       const int m = it >> 3, oc = it & 7;
-      const int img = m / tpix, rem = m - img * tpix;
-      const int ty = rem / a.TW, tx = rem - ty * a.TW;
-      int n, oy0, ox0;
-      const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
-      const int oy = oy0 + ty, ox = ox0 + tx;
+      int pg;
+      if constexpr (PLAN) {
+        pg = plan_g[rep];
+      } else {
+        const int img = m / tpix, rem = m - img * tpix;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        pg = img < a.NI ? (img | (ty << 8) | (tx << 20)) : -1;
+      }
+      const int4 si = *reinterpret_cast<const int4*>(slot_info[pg < 0 ? 0 : (pg & 255)]);
+      const int n = si.x;
+      const bool sv = si.w != 0;
+      const int oy = si.y + ((pg >> 8) & 4095), ox = si.z + (pg >> 20);
       const int c0 = co_base + oc * 8;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (img < a.NI && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+      if (pg >= 0 && sv && oy < d.OH && ox < d.OW && c0 < d.Cout) {
         const float* src = a.gy + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.Cout + c0;
         if (a.vecB && c0 + 8 <= d.Cout) {
           const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
@@ -1152,8 +1200,9 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   const bool quad = a.ntaps <= 9;
   TileChoice t;
   if (quad) {
-    // 192 halo positions x 256 B + 32 KiB output-gradient tile = 80 KiB: two workgroups per CU
-    t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, 128, 192, 12.0);
+    // split product: 184 halo positions x 256 B + 32 KiB output-gradient tile + 2 KiB slot table = 80 KiB, two
+    // workgroups per CU; the single product needs half of that and takes the 192 positions three items per thread cover
+    t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, 128, nsplit == 3 ? 184 : 192, 12.0);
   } else {
     t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
   }
@@ -1191,7 +1240,7 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
   a.vecB = (d->Cout % 4 == 0) ? 1 : 0;
   a.slot_off = (int)(((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1));
-  const size_t lds = (size_t)a.slot_off + (quad ? 0 : BM * 4 * sizeof(int));   // (the 4-wave kernel keeps no table)
+  const size_t lds = (size_t)a.slot_off + BM * 4 * sizeof(int);   // + the per-patch slot table
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
