@@ -101,9 +101,17 @@ def north_star_probes(device, models):
     # argmax byte per pooled element for the backward pass (the full-resolution stem output is an implementation
     # detail: whatever of it an implementation writes and re-reads shows up as time, not as algorithmic bytes)
     alg = B * T * H * H * 4 + B * T * oh * oh * 64 * 5
+    # what this implementation moves in train mode: the clip, the full-resolution pre-BN stem output written once
+    # (batch statistics need the whole batch before anything can be normalised, and the backward pass needs the map)
+    # and read once by the fused BN + PReLU + max-pool pass, the pooled map and its argmax bytes
+    moved = B * T * H * H * 4 + 2 * B * T * (H // 2) * (H // 2) * 64 * 4 + B * T * oh * oh * 64 * 5
     out['frontend'] = dict(stage='Conv3d stem + BN3d + PReLU + MaxPool3d (visual_front.py:11-14), train mode',
                            ms=round(dt * 1e3, 3), algorithmic_bytes=alg, achieved_GBps=round(alg / dt / 1e9, 1),
-                           peak_GBps=8000.0, frac=round(alg / dt / 8e12, 4))
+                           peak_GBps=8000.0, frac=round(alg / dt / 8e12, 4), moved_bytes=moved,
+                           moved_GBps=round(moved / dt / 1e9, 1), moved_frac=round(moved / dt / 8e12, 4),
+                           issued_mfma_tflops=round(3 * 2.0 * B * T * (H // 2) * (H // 2) * 64 * 288 / dt / 1e12, 1),
+                           note='three bf16 MFMAs per product over 5x7x7 taps (padded to 288): the stem kernel is '
+                                'bound by the matrix cores and LDS, not by HBM')
     att = models['gen'].att1
     ctx = torch.randn(B, T, 512, device=device)
     g1 = torch.randn(B, 20, T, 128, device=device)
