@@ -272,13 +272,7 @@ size_t lds_bytes(int S, bool bwd) {
 extern "C" int vca_attention_fwd_f32(int B, int Tq, int S, int D, const float* q, const float* k, const float* v,
                                      const int* lens, float scale, float* ctx, float* probs, void* stream) {
   VCA_CHECK_ARG(B > 0 && Tq > 0 && S > 0 && S <= MAXS && D == DH && q && k && v && lens && ctx && probs);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
+  VCA_MAX_LDS(attn_fwd_kernel);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((Tq + QT - 1) / QT, B), dim3(256), lds_bytes(S, false), (hipStream_t)stream,
                      Tq, S, q, k, v, lens, scale, ctx, probs);
   return vca_launch_status();
@@ -288,13 +282,7 @@ extern "C" int vca_attention_bwd_f32(int B, int Tq, int S, int D, const float* d
                                      const float* v, const float* probs, float scale, float* dq, float* dk, float* dv,
                                      void* stream) {
   VCA_CHECK_ARG(B > 0 && Tq > 0 && S > 0 && S <= MAXS && D == DH && dctx && q && k && v && probs && dq && dk && dv);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
+  VCA_MAX_LDS(attn_bwd_kernel);
   hipStream_t s = (hipStream_t)stream;
   vca_zero_async(dk, (size_t)B * S * D, s);
   vca_zero_async(dv, (size_t)B * S * D, s);

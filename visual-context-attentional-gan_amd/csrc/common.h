@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/vca_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -11,6 +13,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VCA_CHECK_ARG(cond) \
   do {                      \
     if (!(cond)) return -22; \
+  } while (0)
+
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once per DEVICE (the attribute lives with the
+// device's copy of the function), and library calls may come from several host threads.  `done` is the call site's
+// own bit mask of devices already served.  Returns 0 or a hipError_t.
+static inline int vca_max_lds_once(const void* kernel, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+#define VCA_MAX_LDS(kernel)                                                             \
+  do {                                                                                  \
+    static std::atomic<unsigned long long> done_{0};                                    \
+    const int e_ = vca_max_lds_once(reinterpret_cast<const void*>(kernel), done_);      \
+    if (e_) return e_;                                                                  \
   } while (0)
 
 static inline int vca_launch_status() {

@@ -1154,13 +1154,7 @@ template <int BN, int WM, int WN, int NSPLIT>
 int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
   auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
   const size_t lds = halo + 2 * (size_t)BN * (NSPLIT == 3 ? 128 : 64);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  VCA_MAX_LDS(kern);
   // few output tiles but a deep reduction (the discriminators' 5x5 heads on 5x18 maps): split the channel slices
   // over blockIdx.z so the launch covers the chip; partial sums meet in y through fp32 atomics
   a.ksplit = 1;
@@ -1242,20 +1236,12 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.slot_off = (int)(((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1));
   const size_t lds = (size_t)a.slot_off + BM * 4 * sizeof(int);   // + the per-patch slot table
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_done = false;
-  if (!attr_done) {
-    const void* ks[6] = {reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<3>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_quad_kernel<1>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, true>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<3, false>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, true>),
-                         reinterpret_cast<const void*>(conv_bf16_wgrad_kernel<1, false>)};
-    for (int i = 0; i < 6; ++i) {
-      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-    }
-    attr_done = true;
-  }
+  VCA_MAX_LDS(conv_bf16_wgrad_quad_kernel<3>);
+  VCA_MAX_LDS(conv_bf16_wgrad_quad_kernel<1>);
+  VCA_MAX_LDS((conv_bf16_wgrad_kernel<3, true>));
+  VCA_MAX_LDS((conv_bf16_wgrad_kernel<3, false>));
+  VCA_MAX_LDS((conv_bf16_wgrad_kernel<1, true>));
+  VCA_MAX_LDS((conv_bf16_wgrad_kernel<1, false>));
   // many taps: whole taps per wave (output-gradient fragments stay in registers); few taps: balanced unit runs
   const bool rr = a.ntaps > 16;
   const dim3 grid(out_tiles, split), blk(512);

@@ -199,16 +199,8 @@ extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const f
   const long long npatch = (long long)B * T * tiles_y * tiles_x;
   VCA_CHECK_ARG(npatch < (1ll << 31));
   const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + (size_t)4 * HIMG * 2 + 16;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    attr = true;
-  }
+  VCA_MAX_LDS(stem_fwd_kernel<3>);
+  VCA_MAX_LDS(stem_fwd_kernel<1>);
   int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo images 64 KiB)
   if (grid > npatch) grid = (int)npatch;
   const __bf16* wp = reinterpret_cast<const __bf16*>(wpack);

@@ -249,16 +249,7 @@ extern "C" int vca_sync_nce_fwd_f32(int B, int T, int C, const float* v, const f
                                     float* stats, float* loss, void* stream) {
   VCA_CHECK_ARG(B > 0 && T > 0 && T <= MAXT && C > 0 && v && a && S && stats && loss && temp > 0.f);
   const size_t lds = ((size_t)T * T + 2 * (size_t)T * (KC + 1) + 2 * T + THR / 64) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_nce_fwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_nce_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    attr = true;
-  }
+  VCA_MAX_LDS(sync_nce_fwd_kernel);
   hipLaunchKernelGGL(sync_nce_fwd_kernel, dim3(B), dim3(THR), lds, (hipStream_t)stream, T, C, v, a, 1.f / temp, S,
                      stats, loss);
   return vca_launch_status();
@@ -269,13 +260,7 @@ extern "C" int vca_sync_nce_bwd_f32(int B, int T, int C, const float* v, const f
                                     void* stream) {
   VCA_CHECK_ARG(B > 0 && T > 0 && T <= MAXT && C > 0 && v && a && S && stats && gloss && temp > 0.f && (dv || da));
   const size_t lds = ((size_t)T * T + 2 * T) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_nce_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
+  VCA_MAX_LDS(sync_nce_bwd_kernel);
   hipLaunchKernelGGL(sync_nce_bwd_kernel, dim3(B), dim3(THR), lds, (hipStream_t)stream, T, C, v, a, S, stats, gloss,
                      1.f / temp, dv, da);
   return vca_launch_status();
