@@ -43,7 +43,9 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, __bf16* __r
   dst[CO * WROW + i] = (__bf16)(v - (float)h);
 }
 
-template <int NSPLIT>
+// VEC: W is a multiple of 4, so that a group of 4 halo columns (the halo starts at a multiple of 4) is one aligned
+// float4 that lies entirely inside or outside the frame: a quarter of the loads, bounds tests and LDS stores.
+template <int NSPLIT, bool VEC>
 __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int W, int OH, int OW,
                                                        const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                        float* __restrict__ y, float* __restrict__ stats,
@@ -64,16 +66,19 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
   const int ty = wave * 2 + (lr >> 4), tx = lr & 15;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 
-  // halo staging plan of this thread: NL elements i = tid + NTHR*j, decomposed once into (kt, row, column)
-  constexpr int NL = (HALO + NTHR - 1) / NTHR;
+  // halo staging plan of this thread: NL items i = tid + NTHR*j (one element, or 4 consecutive columns with VEC),
+  // decomposed once into (kt, row, column)
+  constexpr int EPI = VEC ? 4 : 1;                        // elements per item
+  constexpr int NITEM = HALO / EPI;
+  constexpr int NL = (NITEM + NTHR - 1) / NTHR;
   int plan[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     const int i = tid + NTHR * j;
-    const int c = i % HC, rr = i / HC;
-    plan[j] = i < HALO ? ((rr / HR) | ((rr % HR) << 8) | (c << 16)) : -1;
+    const int c = (i % (HC / EPI)) * EPI, rr = i / (HC / EPI);
+    plan[j] = i < NITEM ? ((rr / HR) | ((rr % HR) << 8) | (c << 16)) : -1;
   }
-  float hv[NL];
+  float hv[NL][EPI];
   auto issue = [&](int patch) {   // all loads of the patch's halo are issued back to back (kept in flight)
     int r = patch;
     const int tix = r % tiles_x; r /= tiles_x;
@@ -85,10 +90,14 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
     for (int j = 0; j < NL; ++j) {
       const int pl = plan[j];
       const int it = t + (pl & 255) - 2, iy = y0 + ((pl >> 8) & 255), ix = x0 + (pl >> 16);
-      float v = 0.f;
-      if (pl >= 0 && it >= 0 && it < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = x[(((size_t)b * T + it) * H + iy) * W + ix];
-      hv[j] = v;
+      const bool ok = pl >= 0 && it >= 0 && it < T && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      if constexpr (VEC) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(x + (((size_t)b * T + it) * H + iy) * W + ix);
+        hv[j][0] = v.x; hv[j][1] = v.y; hv[j][2] = v.z; hv[j][3] = v.w;
+      } else {
+        hv[j][0] = ok ? x[(((size_t)b * T + it) * H + iy) * W + ix] : 0.f;
+      }
     }
   };
 
@@ -106,15 +115,33 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
       if (plan[j] >= 0) {
         const int pl = plan[j];
         const int c = pl >> 16, rr = (pl & 255) * HR + ((pl >> 8) & 255);
-        const float v = hv[j];
-        const __bf16 h = (__bf16)v;
         const int o = rr * HC2 + c;
-        h_hi[o] = h;
-        h_hi[HIMG + o + 2] = h;
-        if (NSPLIT == 3) {
-          const __bf16 l = (__bf16)(v - (float)h);
-          h_lo[o] = l;
-          h_lo[HIMG + o + 2] = l;
+        if constexpr (VEC) {
+          // o is a multiple of 4 elements: one 8-byte store into copy 0, two 4-byte stores into the shifted copy
+          union { __bf16 e[4]; uint2 u; unsigned int w[2]; } h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h.e[e] = (__bf16)hv[j][e];
+            l.e[e] = (__bf16)(hv[j][e] - (float)h.e[e]);
+          }
+          *reinterpret_cast<uint2*>(h_hi + o) = h.u;
+          *reinterpret_cast<unsigned int*>(h_hi + HIMG + o + 2) = h.w[0];
+          *reinterpret_cast<unsigned int*>(h_hi + HIMG + o + 4) = h.w[1];
+          if (NSPLIT == 3) {
+            *reinterpret_cast<uint2*>(h_lo + o) = l.u;
+            *reinterpret_cast<unsigned int*>(h_lo + HIMG + o + 2) = l.w[0];
+            *reinterpret_cast<unsigned int*>(h_lo + HIMG + o + 4) = l.w[1];
+          }
+        } else {
+          const float v = hv[j][0];
+          const __bf16 h = (__bf16)v;
+          h_hi[o] = h;
+          h_hi[HIMG + o + 2] = h;
+          if (NSPLIT == 3) {
+            const __bf16 l = (__bf16)(v - (float)h);
+            h_lo[o] = l;
+            h_lo[HIMG + o + 2] = l;
+          }
         }
       }
     __syncthreads();
@@ -199,17 +226,23 @@ extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const f
   const long long npatch = (long long)B * T * tiles_y * tiles_x;
   VCA_CHECK_ARG(npatch < (1ll << 31));
   const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + (size_t)4 * HIMG * 2 + 16;
-  VCA_MAX_LDS(stem_fwd_kernel<3>);
-  VCA_MAX_LDS(stem_fwd_kernel<1>);
+  VCA_MAX_LDS((stem_fwd_kernel<3, true>));
+  VCA_MAX_LDS((stem_fwd_kernel<1, true>));
+  VCA_MAX_LDS((stem_fwd_kernel<3, false>));
+  VCA_MAX_LDS((stem_fwd_kernel<1, false>));
   int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo images 64 KiB)
   if (grid > npatch) grid = (int)npatch;
   const __bf16* wp = reinterpret_cast<const __bf16*>(wpack);
-  if (nsplit == 3)
-    hipLaunchKernelGGL(stem_fwd_kernel<3>, dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, x, wp,
-                       y, stats, tiles_y, tiles_x, (int)npatch);
-  else
-    hipLaunchKernelGGL(stem_fwd_kernel<1>, dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, x, wp,
-                       y, stats, tiles_y, tiles_x, (int)npatch);
+  const bool vec = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#define LAUNCH_STEM(NS, V)                                                                                          \
+  hipLaunchKernelGGL((stem_fwd_kernel<NS, V>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, \
+                     x, wp, y, stats, tiles_y, tiles_x, (int)npatch)
+  if (nsplit == 3) {
+    if (vec) LAUNCH_STEM(3, true); else LAUNCH_STEM(3, false);
+  } else {
+    if (vec) LAUNCH_STEM(1, true); else LAUNCH_STEM(1, false);
+  }
+#undef LAUNCH_STEM
   return vca_launch_status();
 }
 
