@@ -937,6 +937,240 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-wave form of the quadrant kernel (single product).  On the large maps a launch of the 4-wave kernel is the sum
+// of its phases: the global loads of a patch run at the HBM's streaming rate for as long as they last (44 % of the
+// launch), then conversion, then the MFMAs, and its 144 accumulator registers leave no room to fetch a patch ahead.
+// Here two groups of four waves share the quadrants and split the taps (at most 5 each: 80 accumulator registers),
+// 512 threads halve the staging items per thread, and the raw fp32 values of the NEXT patch are fetched into
+// registers right before the MFMA phase of the current one, so the loads run under it; half as many workgroups also
+// issue half as many final atomics.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_quad8_kernel(WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAXT8 = 5;
+  const vca_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quadrant = wave & 3, tg = __builtin_amdgcn_readfirstlane(wave >> 2);   // tg: wave-uniform, kept scalar
+  const int cih = quadrant >> 1, coh = quadrant & 1;
+  const int npos_total = a.NI * a.NPOS;
+  unsigned char* halo_hi = smem;                                   // [2 ci halves][position][32 ci]
+  unsigned char* gy_hi = halo_hi + 2 * npos_total * 64;            // [2 co halves][pixel][32 co]
+  int (*slot_info)[4] = reinterpret_cast<int (*)[4]>(smem + a.slot_off);   // two tables of [BM]: n, oy0, ox0, valid
+
+  const int cot = blockIdx.x % a.co_tiles, cit = blockIdx.x / a.co_tiles;
+  const int ci_base = cit * 64, co_base = cot * 64;
+  const int He = d.Hin << d.ups, We = d.Win << d.ups;
+  const int tpix = a.TH * a.TW;
+  const int t_half = (a.ntaps + 1) >> 1;
+  const int t_beg = tg ? t_half : 0, t_end = tg ? a.ntaps : t_half;
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;   // transposed-read geometry of this lane
+  const int kq16 = 8 * g + q, c16sel = p >> 1, c16byte = (p & 1) * 8;
+  int pk16[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = (s >> 1) * 32 + kq16 + 4 * (s & 1);
+    const int img = k / tpix, rem = k - img * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    pk16[s] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
+  }
+  f32x4 acc16[MAXT8][2][2];
+#pragma unroll
+  for (int t = 0; t < MAXT8; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[t][i >> 1][i & 1][r] = 0.f;
+
+  const bool do_bias = a.bias_grad != nullptr && cit == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const unsigned char* my_hh = halo_hi + cih * npos_total * 64;
+  const unsigned char* my_gh = gy_hi + coh * BM * 64;
+
+  // staging plan (see the 4-wave kernel): 2 halo items (position, 16-channel quarter) and 2 output-gradient items
+  // (pixel, 8-channel eighth) per thread, packed as slot | a << 8 | b << 20
+  int plan_h[2], plan_g[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int pos = (tid + k * 512) >> 2;
+    const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
+    const int hy = rp / a.HW, hx = rp - hy * a.HW;
+    plan_h[k] = (tid + k * 512 < npos_total * 4) ? (img | (hy << 8) | (hx << 20)) : -1;
+    const int m = (tid + k * 512) >> 3;
+    const int gi = m / tpix, rem = m - gi * tpix;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    plan_g[k] = gi < a.NI ? (gi | (ty << 8) | (tx << 20)) : -1;
+  }
+
+  float4 ph[2][4], pg[2][2];
+  auto write_slots = [&](int pt, int tbl) {
+    if (tid < a.NI) {
+      int n, oy0, ox0;
+      const bool sv = slot_origin(pt * a.NI + tid, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+      int* si = slot_info[tbl * BM + tid];
+      si[0] = n; si[1] = oy0; si[2] = ox0; si[3] = sv;
+    }
+  };
+  auto fetch = [&](int tbl) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) ph[k][qq] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (plan_h[k] >= 0) {
+        const int qtr = (tid + k * 512) & 3;
+        const int img = plan_h[k] & 255, hy = (plan_h[k] >> 8) & 4095, hx = plan_h[k] >> 20;
+        const int4 si = *reinterpret_cast<const int4*>(slot_info[tbl * BM + img]);
+        int vy = si.y * d.stride + hy - d.pad_h, vx = si.z * d.stride + hx - d.pad_w;
+        const bool ok = si.w != 0 && vy >= 0 && vx >= 0 && vy < He && vx < We;
+        vy >>= d.ups;
+        vx >>= d.ups;
+        const int ci0 = ci_base + qtr * 16;
+        if (ok && ci0 < d.Cin) {
+          const float* src = a.x + ((size_t)(si.x * d.Hin + vy) * d.Win + vx) * d.Cin + ci0;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) ph[k][qq] = *reinterpret_cast<const float4*>(src + 4 * qq);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      pg[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pg[k][1] = pg[k][0];
+      const int oc = (tid + k * 512) & 7;
+      const int pl = plan_g[k];
+      if (pl >= 0) {
+        const int4 si = *reinterpret_cast<const int4*>(slot_info[tbl * BM + (pl & 255)]);
+        const int oy = si.y + ((pl >> 8) & 4095), ox = si.z + (pl >> 20);
+        const int c0 = co_base + oc * 8;
+        if (si.w != 0 && oy < d.OH && ox < d.OW && c0 < d.Cout) {
+          const float* src = a.gy + ((size_t)(si.x * d.OH + oy) * d.OW + ox) * d.Cout + c0;
+          pg[k][0] = *reinterpret_cast<const float4*>(src);
+          pg[k][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+      }
+    }
+  };
+
+  const int pt_beg = blockIdx.y * a.tiles_per_block;
+  const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
+  if (pt_beg < pt_end) {
+    write_slots(pt_beg, 0);
+    __syncthreads();
+    fetch(0);
+  }
+  for (int pt = pt_beg; pt < pt_end; ++pt) {
+    const int cur = (pt - pt_beg) & 1;
+    if (pt + 1 < pt_end) write_slots(pt + 1, cur ^ 1);
+    __syncthreads();   // the previous patch's fragments have been read; the next patch's slot table is visible
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (plan_h[k] < 0) break;
+      const int it = tid + k * 512;
+      const int pos = it >> 2, qtr = it & 3;
+      float v[16];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        v[4 * qq] = ph[k][qq].x; v[4 * qq + 1] = ph[k][qq].y; v[4 * qq + 2] = ph[k][qq].z; v[4 * qq + 3] = ph[k][qq].w;
+      }
+      const int sw = (pos >> 2) & 3, sub = qtr & 1;
+      const int base = (qtr >> 1) * npos_total * 64 + pos * 64;
+      uint4 h0, l0, h1, l1;
+      split8(v, h0, l0);
+      split8(v + 8, h1, l1);
+      *reinterpret_cast<uint4*>(halo_hi + base + (((2 * sub) ^ sw) << 4)) = h0;
+      *reinterpret_cast<uint4*>(halo_hi + base + (((2 * sub + 1) ^ sw) << 4)) = h1;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = tid + k * 512;
+      const int m = it >> 3, oc = it & 7;
+      const float v[8] = {pg[k][0].x, pg[k][0].y, pg[k][0].z, pg[k][0].w, pg[k][1].x, pg[k][1].y, pg[k][1].z, pg[k][1].w};
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += v[j];
+      }
+      const int sw = (m >> 2) & 3, qt = oc & 3;
+      const int base = (oc >> 2) * BM * 64 + m * 64 + ((qt ^ sw) << 4);
+      uint4 h0, l0;
+      split8(v, h0, l0);
+      *reinterpret_cast<uint4*>(gy_hi + base) = h0;
+    }
+    __syncthreads();
+    if (pt + 1 < pt_end) fetch(cur ^ 1);   // in flight under the MFMAs below
+
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x8 bh[2][2];              // [32-pixel step][co half of the quadrant]
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int k0 = (hf * 2 + st) * 32 + kq16, k1 = k0 + 4;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int o0 = k0 * 64 + (((2 * ch + c16sel) ^ ((k0 >> 2) & 3)) << 4) + c16byte;
+          const int o1 = k1 * 64 + (((2 * ch + c16sel) ^ ((k1 >> 2) & 3)) << 4) + c16byte;
+          bh[st][ch] = tr_read8(my_gh + o0, my_gh + o1);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < MAXT8; ++tt) {
+        const int t = t_beg + tt;
+        if (t < t_end) {
+          const int kh = t / d.KW, kw = t - kh * d.KW;
+          int tapoff = kh * a.HW + kw;
+          asm volatile("" : "+s"(tapoff));
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            const int s32 = hf * 2 + st;
+            const int p0 = pk16[2 * s32] + tapoff, p1 = pk16[2 * s32 + 1] + tapoff;
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+              const int o0 = p0 * 64 + (((2 * ih + c16sel) ^ ((p0 >> 2) & 3)) << 4) + c16byte;
+              const int o1 = p1 * 64 + (((2 * ih + c16sel) ^ ((p1 >> 2) & 3)) << 4) + c16byte;
+              const bf16x8 ah = tr_read8(my_hh + o0, my_hh + o1);
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch)
+                acc16[tt][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[st][ch], acc16[tt][ih][ch], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (do_bias) {
+    float* bsh = reinterpret_cast<float*>(smem);   // the staged images are not needed any more
+    __syncthreads();
+    if (tid < 64) bsh[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&bsh[(tid & 7) * 8 + j], bsum[j]);
+    __syncthreads();
+    if (tid < 64 && co_base + tid < d.Cout) atomicAdd(a.bias_grad + co_base + tid, bsh[tid]);
+  }
+
+  // ---- accumulate into dW: 16 x 16 tiles, col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+  for (int tt = 0; tt < MAXT8; ++tt) {
+    const int t = t_beg + tt;
+    if (t < t_end) {
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int co = co_base + coh * 32 + ch * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = ci_base + cih * 32 + ih * 16 + 4 * g + r;
+            if (ci < d.Cin && co < d.Cout)
+              atomicAdd(a.dw + ((size_t)t * d.Cin + ci) * a.Cout4 + co, acc16[tt][ih][ch][r]);
+          }
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing: fp32 [Cout][Cin][taps] -> bf16 [tap][chunk][npad][hi 32 | lo 32]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float s2_weight(const float* __restrict__ src, int Cin, int tap, int n, int co);
@@ -1215,7 +1449,9 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   // Pixel split: every workgroup ends with one atomic add per accumulator, which costs about as much as `fin`
   // patches of MFMA work, and the launch runs in ceil(workgroups / resident slots) rounds.  Take the split that
   // minimises rounds * (patches per workgroup + fin).
-  const int slots = quad ? 512 : 256;            // 2 x 4-wave or 1 x 8-wave workgroups per CU
+  // 8-wave form of the quadrant kernel: single product, whole 16-byte pieces, no prologue on the input
+  const bool quad8 = quad && nsplit == 1 && d->Cin % 16 == 0 && d->Cout % 8 == 0 && !in_scale && d->act == 0;
+  const int slots = (quad && !quad8) ? 512 : 256;   // 2 x 4-wave or 1 x 8-wave workgroups per CU
   const double fin = quad ? 2.0 : 1.0;
   int split = 1;
   double best_cost = 1e300;
@@ -1234,8 +1470,9 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
   a.vecB = (d->Cout % 4 == 0) ? 1 : 0;
   a.slot_off = (int)(((size_t)a.NI * a.NPOS * 64 + BM * 64) * (nsplit == 3 ? 2 : 1) * (quad ? 2 : 1));
-  const size_t lds = (size_t)a.slot_off + BM * 4 * sizeof(int);   // + the per-patch slot table
+  const size_t lds = (size_t)a.slot_off + BM * 4 * sizeof(int) * (quad8 ? 2 : 1);   // + the per-patch slot table(s)
   hipStream_t s = (hipStream_t)stream;
+  VCA_MAX_LDS(conv_bf16_wgrad_quad8_kernel);
   VCA_MAX_LDS(conv_bf16_wgrad_quad_kernel<3>);
   VCA_MAX_LDS(conv_bf16_wgrad_quad_kernel<1>);
   VCA_MAX_LDS((conv_bf16_wgrad_kernel<3, true>));
@@ -1245,7 +1482,9 @@ extern "C" int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const flo
   // many taps: whole taps per wave (output-gradient fragments stay in registers); few taps: balanced unit runs
   const bool rr = a.ntaps > 16;
   const dim3 grid(out_tiles, split), blk(512);
-  if (quad) {
+  if (quad8) {
+    hipLaunchKernelGGL(conv_bf16_wgrad_quad8_kernel, grid, dim3(512), lds, s, a);
+  } else if (quad) {
     if (nsplit == 3) hipLaunchKernelGGL((conv_bf16_wgrad_quad_kernel<3>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_bf16_wgrad_quad_kernel<1>), grid, dim3(256), lds, s, a);
   } else if (nsplit == 3) {
