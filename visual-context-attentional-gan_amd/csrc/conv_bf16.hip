@@ -84,6 +84,11 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 // launch is 17-19 % shorter, without the weight tiles 11-14 %.
 __device__ __forceinline__ int sw16(int row) { return ((row >> 2) & 1) << 1; }
 
+// x / d for 0 <= x < 1024 and 1 <= d <= 512 from inv = 1.0f / d: four full-rate instructions instead of the ~40 of an
+// integer division.  (x + 0.5) / d is at least 0.5 / d >= 9.7e-4 away from an integer, the two fp32 roundings move the
+// product by less than 3e-4.
+__device__ __forceinline__ int small_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
 template <int BN, int WM, int WN, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,12 +110,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   const int He = d.Hin << d.ups, We = d.Win << d.ups;
   const int tpix = a.TH * a.TW;
 
+  const float inv_tpix = 1.0f / (float)tpix, inv_tw = 1.0f / (float)a.TW;
   int hb[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = wm * WTM + i * 16 + lr;
-    const int img = m / tpix, rem = m - img * tpix;
-    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    const int img = small_div(m, inv_tpix), rem = m - img * tpix;
+    const int ty = small_div(rem, inv_tw), tx = rem - ty * a.TW;
     hb[i] = img < a.NI ? img * a.NPOS + ty * d.stride * a.HW + tx * d.stride : 0;
   }
   int boff[NT];
@@ -149,7 +155,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   };
   auto wait_b = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
+  // Source offset of each halo item of this thread, the same for every channel slice.  The slots' (image, first input
+  // row, first input column, valid) are worked out once per workgroup, in the still idle weight buffers; the
+  // position -> (slot, halo row, halo column) split of an item uses small_div.
   constexpr int NHI = (2 * MAXPOS + 255) / 256;
+  int4* slot_tab = reinterpret_cast<int4*>(bbase);
+  if (tid < a.NI) {
+    int n, oy0, ox0;
+    const bool ok = slot_origin(sid0 + tid, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
+    slot_tab[tid] = make_int4(n, oy0 * d.stride - d.pad_h, ox0 * d.stride - d.pad_w, ok ? 1 : 0);
+  }
+  __syncthreads();
+  const float inv_npos = 1.0f / (float)a.NPOS, inv_hw = 1.0f / (float)a.HW;
   long long hsrc[NHI];
 #pragma unroll
   for (int k = 0; k < NHI; ++k) {
@@ -157,16 +174,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     hsrc[k] = -1;
     if (it < npos_total * 2) {
       const int pos = it >> 1;
-      const int img = pos / a.NPOS, rp = pos - img * a.NPOS;
-      const int hy = rp / a.HW, hx = rp - hy * a.HW;
+      const int img = small_div(pos, inv_npos), rp = pos - img * a.NPOS;
+      const int hy = small_div(rp, inv_hw), hx = rp - hy * a.HW;
       if (hx >= a.HWv || hy >= a.HH) {   // padding of the row / slot pitch: never read by a fragment, never staged
         hsrc[k] = -2;
         continue;
       }
-      int n, oy0, ox0;
-      bool ok = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, n, oy0, ox0);
-      int vy = oy0 * d.stride + hy - d.pad_h, vx = ox0 * d.stride + hx - d.pad_w;
-      ok = ok && vy >= 0 && vx >= 0;
+      const int4 st = slot_tab[img];
+      const int n = st.x;
+      int vy = st.y + hy, vx = st.z + hx;
+      bool ok = st.w != 0 && vy >= 0 && vx >= 0;
       if (d.dil > 1) {
         ok = ok && (vy % d.dil == 0) && (vx % d.dil == 0);
         vy /= d.dil;
@@ -285,8 +302,44 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 
   // ---- epilogue: D[row][col]: col = lane&15, row = 4*(lane>>4) + r
   // d2s_h > 0: the GEMM's Cout columns are 4 groups (ry, rx) of Cout/4 channels and column (ry, rx, c) of output
-  // pixel (oy, ox) is element c of pixel (2*oy + ry, 2*ox + rx) of a [N][d2s_h][d2s_w][Cout/4] tensor
+  // pixel (oy, ox) is element c of pixel (2*oy + ry, 2*ox + rx) of a [N][d2s_h][d2s_w][Cout/4] tensor.
+  // The output pixel of each of the 128 GEMM rows is worked out once, by the first 128 threads, into the (now dead)
+  // halo image: .x = index of the pixel (of pixel (2*oy, 2*ox) for d2s), -1 for a row without output; .y = d2s only:
+  // bit 0 / bit 1 set when row 2*oy + 1 / column 2*ox + 1 exists.
+  int2* row_tab = reinterpret_cast<int2*>(smem);
+  if (tid < BM) {
+    const int img = small_div(tid, inv_tpix), rem = tid - img * tpix;
+    const int ty = small_div(rem, inv_tw), tx = rem - ty * a.TW;
+    int nn, oy0, ox0;
+    const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, nn, oy0, ox0);
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    int2 e = make_int2(-1, 0);
+    if (img < a.NI && sv && oy < d.OH && ox < d.OW) {
+      if (d.d2s_h) {
+        e.x = (nn * d.d2s_h + 2 * oy) * d.d2s_w + 2 * ox;
+        e.y = (2 * oy + 1 < d.d2s_h ? 1 : 0) | (2 * ox + 1 < d.d2s_w ? 2 : 0);
+      } else {
+        e.x = (nn * d.OH + oy) * d.OW + ox;
+      }
+    }
+    row_tab[tid] = e;
+  }
+  __syncthreads();
   const int cq = d.Cout >> 2;
+  const int cmul = d.d2s_h ? cq : d.Cout;   // channels per pixel of the output tensor
+  size_t rbase[MT][4];
+  int rflag[MT][4];   // -1: no output
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int4 t0 = *reinterpret_cast<const int4*>(row_tab + wm * WTM + i * 16 + 4 * lc);
+    const int4 t1 = *reinterpret_cast<const int4*>(row_tab + wm * WTM + i * 16 + 4 * lc + 2);
+    const int px[4] = {t0.x, t0.z, t1.x, t1.z}, fl[4] = {t0.y, t0.w, t1.y, t1.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rbase[i][r] = (size_t)max(px[r], 0) * cmul;
+      rflag[i][r] = px[r] < 0 ? -1 : fl[r];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * WTN + j * 16 + lr;
@@ -294,28 +347,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
     const int grp = d.d2s_h ? n / cq : 0;
     const int nc = n - grp * cq, ry = grp >> 1, rx = grp & 1;
+    const int need = d.d2s_h ? (ry | (rx << 1)) : 0;                 // neighbours the column's sub-pixel needs
+    const int coff = d.d2s_h ? (ry * d.d2s_w + rx) * cq + nc : n;    // offset of the column from the row's base
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = wm * WTM + i * 16 + 4 * lc + r;
-        const int img = m / tpix, rem = m - img * tpix;
-        const int ty = rem / a.TW, tx = rem - ty * a.TW;
-        int nn, oy0, ox0;
-        const bool sv = slot_origin(sid0 + img, a.nsub, a.tiles_x, a.tiles_y, a.TH, a.TW, nn, oy0, ox0);
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        if (nv && img < a.NI && sv && oy < d.OH && ox < d.OW) {
+        if (nv && rflag[i][r] >= 0) {
           float v = acc[i][j][r];
           s1 += v;
           s2 += v * v;
           v += b;
-          size_t o = ((size_t)(nn * d.OH + oy) * d.OW + ox) * d.Cout + n;
-          if (d.d2s_h) {
-            const int py = 2 * oy + ry, px = 2 * ox + rx;
-            if (py >= d.d2s_h || px >= d.d2s_w) continue;
-            o = ((size_t)(nn * d.d2s_h + py) * d.d2s_w + px) * cq + nc;
-          }
+          if ((rflag[i][r] & need) != need) continue;
+          const size_t o = rbase[i][r] + coff;
           if (a.ksplit > 1) {
             atomicAdd(a.y + o, v);
           } else {
