@@ -106,6 +106,16 @@ int vca_unpack_wgrad_batch_f32(const vca_unpack_desc* table, int ndesc, int tota
 int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack, const float* bias,
                       const float* in_scale, const float* in_shift, const float* in_alpha, const float* res,
                       float* y, float* stats, void* stream);
+/* vca_conv_fwd_bf16 with a caller-provided workspace.  Launches with few output tiles and a deep reduction (the
+ * discriminators' 5x5 layers on 5x18 / 10x37 maps, generator.py:286-290) split the channel slices over several
+ * workgroups per tile; with ws (ws_floats >= vca_conv_fwd_bf16_ws_floats(d), fp32, contents irrelevant before and
+ * after) every range stores its partial sums in a slab of ws and a second kernel folds the slabs into y; without it
+ * (ws NULL or too small) the partial sums are added to a zero-filled y with fp32 atomics, as vca_conv_fwd_bf16 does.
+ * vca_conv_fwd_bf16_ws_floats returns 0 for a descriptor whose launch does not split. */
+int vca_conv_fwd_bf16_ws(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack, const float* bias,
+                         const float* in_scale, const float* in_shift, const float* in_alpha, const float* res,
+                         float* y, float* stats, float* ws, long long ws_floats, void* stream);
+long long vca_conv_fwd_bf16_ws_floats(const vca_conv_desc* d);
 /* Split-bf16 variant of vca_conv_wgrad_f32 (same fp32 [tap][Cin][Cout4] output, accumulated with atomics into a
  * zeroed buffer; at most 32 taps).  bias_grad (may be NULL): [Cout] vector to which the column sums of gy, i.e. the
  * gradient of the convolution's bias, are ADDED (fp32, from the output-gradient tiles the kernel stages anyway). */

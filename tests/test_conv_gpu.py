@@ -227,3 +227,43 @@ def test_stride2_input_gradient_subpixel_form(case, prec, tol):
     finally:
         ops.SUBPIXEL_DGRAD = True
     assert rel_err(got, dilated.cpu()) < (1e-5 if prec == 'bf16x3' else 1e-2)
+
+
+@gpu
+@pytest.mark.parametrize('ns', [3, 1])
+@pytest.mark.parametrize('case', [(8, 5, 18, 256, 256, 5, 0), (8, 5, 18, 160, 136, 5, 2), (6, 10, 37, 256, 96, 3, 1)])
+def test_split_reduction_workspace_and_atomics_agree(case, ns):
+    """Few output tiles, deep reduction: the channel slices are split over workgroups.  The workspace form (partial
+    sums in slabs + fold kernel) and the atomics form of the same launch must both match the CPU convolution; the
+    workspace's previous contents must not matter and a too small workspace must fall back to atomics."""
+    from vcagan_amd import _lib, ops
+    from vcagan_amd._lib import ptr, stream, check
+    N, H, W, Cin, Cout, K, p = case
+    g = torch.Generator().manual_seed(sum(case) + ns)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    yr = F.conv2d(x.permute(0, 3, 1, 2), w, b, 1, p).permute(0, 2, 3, 1)
+    ops.set_precision('bf16x3')
+    cfg = ops.ConvCfg(w.shape, x.shape, 1, (p, p), 0)
+    d = cfg.desc()
+    L = _lib.lib()
+    nws = int(L.vca_conv_fwd_bf16_ws_floats(d))
+    assert nws > 0, 'the case is meant to split its reduction'
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    wp = ops._pack(wd, 10)
+    tol = 1e-4 if ns == 3 else 3e-2
+    outs = []
+    for ws in (None, torch.full((nws,), float('nan'), device='cuda'), torch.full((nws // 2,), float('nan'), device='cuda')):
+        y = torch.full(cfg.yshape, float('nan'), device='cuda')
+        check(L.vca_conv_fwd_bf16_ws(d, ns, ptr(xd), wp.data_ptr(), ptr(bd), None, None, None, None, ptr(y), None,
+                                     ptr(ws), 0 if ws is None else ws.numel(), stream()), 'conv_fwd_bf16_ws')
+        torch.cuda.synchronize()
+        assert rel_err(y, yr) < tol
+        outs.append(y)
+    # one summation order per output element in the workspace form: bit-identical from run to run
+    y2 = torch.empty(cfg.yshape, device='cuda')
+    ws = torch.zeros(nws, device='cuda')
+    check(L.vca_conv_fwd_bf16_ws(d, ns, ptr(xd), wp.data_ptr(), ptr(bd), None, None, None, None, ptr(y2), None,
+                                 ptr(ws), nws, stream()), 'conv_fwd_bf16_ws')
+    assert torch.equal(y2, outs[1])

@@ -15,7 +15,8 @@ ops.set_precision(sys.argv[9] if len(sys.argv) > 9 else 'bf16x3')
 dev = torch.device('cuda', 0)
 x = torch.randn(N, H, W, Cin, device=dev)
 w = torch.randn(Cout, Cin, K, K, device=dev) * 0.02
-cfg = ops.ConvCfg(w.shape, x.shape, stride, (K // 2, K // 2), 0)
+pad = int(os.environ.get('PAD', K // 2))
+cfg = ops.ConvCfg(w.shape, x.shape, stride, (pad, pad), 0)
 gy = torch.randn(cfg.yshape, device=dev)
 stats = torch.zeros(2, Cout, device=dev) if os.environ.get('STATS') else None
 

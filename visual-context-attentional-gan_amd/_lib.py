@@ -63,6 +63,8 @@ _SIGS = {
     'vca_unpack_wgrad_f32': ([_I, _I, _I, _P, _P, _F, _I, _P], _I),
     'vca_unpack_wgrad_batch_f32': ([_P, _I, _I, _P], _I),
     'vca_conv_fwd_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10, _I),
+    'vca_conv_fwd_bf16_ws': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10 + [_LL, _P], _I),
+    'vca_conv_fwd_bf16_ws_floats': ([ctypes.POINTER(ConvDesc)], _LL),
     'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 8, _I),
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),

@@ -41,7 +41,9 @@ struct HArgs {
   int HWv;                        // halo positions per row that are actually staged (<= HW)
   int tiles_x, tiles_y, nsub;
   int vecA;
-  int ksplit;  // >1: blockIdx.z owns a range of channel slices and adds its partial sums atomically
+  int ksplit;  // >1: blockIdx.z owns a range of channel slices; its partial sums go to slab blockIdx.z of `part`
+  float* part; //     (plain stores, folded into y by sum_slabs_kernel) or, without a workspace, into y with atomics
+  unsigned part_stride;   // floats per slab
 };
 
 // A workgroup's GEMM rows are NI "slots" of TH x TW output pixels.  Slots are consecutive entries of the list of all
@@ -362,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
           if ((rflag[i][r] & need) != need) continue;
           const size_t o = rbase[i][r] + coff;
           if (a.ksplit > 1) {
-            atomicAdd(a.y + o, v);
+            if (a.part) a.part[(size_t)blockIdx.z * a.part_stride + o] = v;
+            else atomicAdd(a.y + o, v);
           } else {
             if (a.res) v += a.res[o];
             a.y[o] = v * d.out_scale;
@@ -1360,6 +1363,31 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_batch_kernel(const vca_p
                  (local / nchunk) * 8, tl);
 }
 
+// y[i] = sum over the S slabs of part[s * stride + i]: folds the partial sums of a split-reduction launch.
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, unsigned stride, int S,
+                                                        float* __restrict__ y, unsigned n) {
+  const unsigned i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 acc = *reinterpret_cast<const float4*>(part + i);
+    for (int s = 1; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * stride + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if ((reinterpret_cast<size_t>(y) & 15) == 0) {
+      *reinterpret_cast<float4*>(y + i) = acc;
+    } else {
+      y[i] = acc.x; y[i + 1] = acc.y; y[i + 2] = acc.z; y[i + 3] = acc.w;
+    }
+  } else {
+    for (unsigned k = i; k < n; ++k) {
+      float acc = part[k];
+      for (int s = 1; s < S; ++s) acc += part[(size_t)s * stride + k];
+      y[k] = acc;
+    }
+  }
+}
+
 struct TileChoice {
   int NI, TH, TW;
 };
@@ -1429,25 +1457,46 @@ TileChoice choose_tile(int N, int OH, int OW, int KH, int KW, int stride, int Co
   return best;
 }
 
+// Number of channel-slice ranges a launch of `blocks` output tiles is split into (1 = no split): few output tiles
+// but a deep reduction (the discriminators' 5x5 layers on 5x18 and 10x37 maps) would leave most of the chip idle.
+inline int choose_ksplit(long long blocks, int nchunk) {
+  if (blocks >= 224 || nchunk < 4) return 1;
+  int ks = (int)((448 + blocks - 1) / blocks);
+  if (ks > nchunk) ks = nchunk;               // down to one 32-channel slice per workgroup
+  const int cpz = (nchunk + ks - 1) / ks;
+  return (nchunk + cpz - 1) / cpz;            // no empty ranges
+}
+
+inline size_t out_floats(const vca_conv_desc& d) {
+  return d.d2s_h ? (size_t)d.N * d.d2s_h * d.d2s_w * (d.Cout / 4) : (size_t)d.N * d.OH * d.OW * d.Cout;
+}
+
 template <int BN, int WM, int WN, int NSPLIT>
-int launch_halo(HArgs a, int gx, int gy, size_t halo, hipStream_t s) {
+int launch_halo(HArgs a, int gx, int gy, size_t halo, float* ws, size_t ws_floats, hipStream_t s) {
   auto kern = conv_bf16_halo_kernel<BN, WM, WN, NSPLIT>;
   const size_t lds = halo + 2 * (size_t)BN * (NSPLIT == 3 ? 128 : 64);
   VCA_MAX_LDS(kern);
-  // few output tiles but a deep reduction (the discriminators' 5x5 heads on 5x18 maps): split the channel slices
-  // over blockIdx.z so the launch covers the chip; partial sums meet in y through fp32 atomics
+  // split reduction: with a workspace every range stores its partial sums in a slab of its own and a second kernel
+  // folds the slabs into y; without one the partial sums meet in a zero-filled y through fp32 atomics (device-scope
+  // atomics are resolved beyond the XCDs' L2s: 15-35 us per launch against 3-5 us for the fold)
   a.ksplit = 1;
-  const long long blocks = (long long)gx * gy;
-  if (blocks < 224 && a.nchunk >= 4 && !a.res && !a.stats && a.d.out_scale == 1.0f) {
-    int ks = (int)((448 + blocks - 1) / blocks);
-    if (ks > a.nchunk) ks = a.nchunk;       // down to one 32-channel slice per workgroup
-    if (ks > 1) {
-      a.ksplit = ks;
-      vca_zero_async(a.y, a.d.d2s_h ? (size_t)a.d.N * a.d.d2s_h * a.d.d2s_w * (a.d.Cout / 4)
-                                    : (size_t)a.d.N * a.d.OH * a.d.OW * a.d.Cout, s);
+  a.part = nullptr;
+  a.part_stride = 0;
+  const size_t total = out_floats(a.d);
+  if (!a.res && !a.stats && a.d.out_scale == 1.0f) a.ksplit = choose_ksplit((long long)gx * gy, a.nchunk);
+  if (a.ksplit > 1) {
+    const size_t stride = (total + 63) / 64 * 64;
+    if (ws && ws_floats >= stride * a.ksplit && stride < (1ull << 32)) {
+      a.part = ws;
+      a.part_stride = (unsigned)stride;
+    } else {
+      vca_zero_async(a.y, total, s);
     }
   }
   hipLaunchKernelGGL(kern, dim3(gx, gy, a.ksplit), dim3(256), lds, s, a);
+  if (a.part)
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, a.part,
+                       a.part_stride, a.ksplit, a.y, (unsigned)total);
   return vca_launch_status();
 }
 
@@ -1573,9 +1622,10 @@ extern "C" int vca_pack_weight_bf16_batch(const vca_pack_desc* table, int ndesc,
   return vca_launch_status();
 }
 
-extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack,
-                                 const float* bias, const float* in_scale, const float* in_shift,
-                                 const float* in_alpha, const float* res, float* y, float* stats, void* stream) {
+extern "C" int vca_conv_fwd_bf16_ws(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack,
+                                    const float* bias, const float* in_scale, const float* in_shift,
+                                    const float* in_alpha, const float* res, float* y, float* stats, float* ws,
+                                    long long ws_floats, void* stream) {
   VCA_CHECK_ARG(d && x && wpack && y && (nsplit == 1 || nsplit == 3));
   VCA_CHECK_ARG(d->N > 0 && d->D == 1 && d->OD == 1 && d->KD == 1 && d->pad_d == 0 && d->Cin > 1 && d->Cout > 0);
   VCA_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->OH > 0 && d->OW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0);
@@ -1609,15 +1659,35 @@ extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float
   a.nsub = d->N * a.tiles_x * a.tiles_y;
   const int gx = (a.nsub + t.NI - 1) / t.NI;
   hipStream_t s = (hipStream_t)stream;
+  const size_t wsf = ws && ws_floats > 0 ? (size_t)ws_floats : 0;
   const size_t halo = (size_t)a.NI * a.NPOS * 64 * (nsplit == 3 ? 2 : 1);
 #define LAUNCH_H(BN_, WM_, WN_)                                                                   \
   do {                                                                                             \
     const int gy = (d->Cout + BN_ - 1) / BN_;                                                      \
-    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3>(a, gx, gy, halo, s)                         \
-                       : launch_halo<BN_, WM_, WN_, 1>(a, gx, gy, halo, s);                        \
+    return nsplit == 3 ? launch_halo<BN_, WM_, WN_, 3>(a, gx, gy, halo, ws, wsf, s)                         \
+                       : launch_halo<BN_, WM_, WN_, 1>(a, gx, gy, halo, ws, wsf, s);                        \
   } while (0)
   if (d->Cout > 64) LAUNCH_H(128, 2, 2);
   else if (d->Cout > 32) LAUNCH_H(64, 2, 2);
   else LAUNCH_H(32, 4, 1);
 #undef LAUNCH_H
+}
+
+extern "C" int vca_conv_fwd_bf16(const vca_conv_desc* d, int nsplit, const float* x, const void* wpack,
+                                 const float* bias, const float* in_scale, const float* in_shift,
+                                 const float* in_alpha, const float* res, float* y, float* stats, void* stream) {
+  return vca_conv_fwd_bf16_ws(d, nsplit, x, wpack, bias, in_scale, in_shift, in_alpha, res, y, stats, nullptr, 0,
+                              stream);
+}
+
+extern "C" long long vca_conv_fwd_bf16_ws_floats(const vca_conv_desc* d) {
+  if (!d || d->N <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0 || d->Cin <= 1 || d->KH <= 0 || d->KW <= 0 ||
+      d->stride <= 0 || d->out_scale != 1.0f)
+    return 0;
+  const TileChoice t = choose_tile(d->N, d->OH, d->OW, d->KH, d->KW, d->stride, d->Cout);
+  const long long nsub = (long long)d->N * ((d->OW + t.TW - 1) / t.TW) * ((d->OH + t.TH - 1) / t.TH);
+  const long long gx = (nsub + t.NI - 1) / t.NI;
+  const int bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+  const int ks = choose_ksplit(gx * ((d->Cout + bn - 1) / bn), (d->Cin + 31) / 32);
+  return ks > 1 ? (long long)((out_floats(*d) + 63) / 64 * 64) * ks : 0;
 }

@@ -166,6 +166,7 @@ class ConvCfg:
         self.ow = (we + 2 * self.pad_w - self.kw) // stride + 1
         self.xshape = tuple(xshape)
         self.yshape = (self.n,) + ((self.od,) if len(xshape) == 5 else ()) + (self.oh, self.ow, self.cout)
+        self.key = (self.wshape, self.xshape, stride, self.pad_h, self.pad_w, ups)
 
     def desc(self, out_scale=1.0):
         return ConvDesc(self.n, self.d, self.hin, self.win, self.cin, self.od, self.oh, self.ow, self.cout,
@@ -215,14 +216,31 @@ def _nsplit(backward=False):
     return {'fp32': 0, 'bf16x3': 3, 'bf16': 1}[_precision[0]]
 
 
+_ws_floats = {}   # (role, geometry) -> workspace floats of that launch
+
+
+def _split_ws(cfg, role, d, device):
+    """(tensor, floats): a workspace for the partial sums of the matrix-core launch of descriptor d, (None, 0) for a
+    launch that does not split its reduction over workgroups.  The size is asked from the library once per geometry.
+    The caller holds the tensor until the launch has been issued (the allocator may hand the memory to the next
+    allocation on the stream as soon as it is released)."""
+    n = _ws_floats.get((role, cfg.key))
+    if n is None:
+        n = _ws_floats[(role, cfg.key)] = int(_lib.lib().vca_conv_fwd_bf16_ws_floats(d))
+    if not n:
+        return None, 0
+    return torch.empty(n, device=device, dtype=torch.float32), n
+
+
 def _conv_fwd_raw(x, w, bias, cfg, stats=None):
     """stats: optional zeroed (2, Cout) tensor receiving per-channel sum / sum of squares of (y - bias)."""
     y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
     d = cfg.desc()
     ns = _nsplit()
     if ns and cfg.cin > 1 and cfg.kd == 1:
-        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
-                                           ptr(y), ptr(stats), stream()), 'conv_fwd_bf16')
+        ws, nws = (None, 0) if stats is not None else _split_ws(cfg, 'fwd', d, x.device)
+        check(_lib.lib().vca_conv_fwd_bf16_ws(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
+                                              ptr(y), ptr(stats), ptr(ws), nws, stream()), 'conv_fwd_bf16')
     else:
         check(_lib.lib().vca_conv_fwd_f32(d, ptr(x), ptr(_pack(w, 0)), ptr(bias), None, None, None, None, ptr(y),
                                           ptr(stats), stream()), 'conv_fwd')
@@ -238,11 +256,14 @@ def _conv_dgrad_raw(gy, w, cfg, res=None):
     fuse = res is not None and not cfg.ups
     r = _c(res) if fuse else None
     if ns and cfg.subpixel_dgrad():
-        check(_lib.lib().vca_conv_fwd_bf16(cfg.subpixel_dgrad_desc(), ns, ptr(gy), _pack(w, 12).data_ptr(), None, None,
-                                           None, None, ptr(r), ptr(gx), None, stream()), 'conv_dgrad_bf16_subpixel')
+        d = cfg.subpixel_dgrad_desc()
+        ws, nws = (None, 0) if fuse else _split_ws(cfg, 'dgrad2', d, gy.device)
+        check(_lib.lib().vca_conv_fwd_bf16_ws(d, ns, ptr(gy), _pack(w, 12).data_ptr(), None, None, None, None, ptr(r),
+                                              ptr(gx), None, ptr(ws), nws, stream()), 'conv_dgrad_bf16_subpixel')
     elif ns and cfg.cout > 1:
-        check(_lib.lib().vca_conv_fwd_bf16(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, ptr(r),
-                                           ptr(gx), None, stream()), 'conv_dgrad_bf16')
+        ws, nws = (None, 0) if fuse else _split_ws(cfg, 'dgrad', d, gy.device)
+        check(_lib.lib().vca_conv_fwd_bf16_ws(d, ns, ptr(gy), _pack(w, 11).data_ptr(), None, None, None, None, ptr(r),
+                                              ptr(gx), None, ptr(ws), nws, stream()), 'conv_dgrad_bf16')
     else:
         check(_lib.lib().vca_conv_fwd_f32(d, ptr(gy), ptr(_pack(w, 1)), None, None, None, None, ptr(r), ptr(gx), None,
                                           stream()), 'conv_dgrad')
