@@ -60,9 +60,11 @@ typedef struct {
 
 /* y = conv(prologue(x), w) + bias (+ res), * out_scale.
  * wpack: [KD*KH*KW][Cin][Cout4] with Cout4 = Cout rounded up to 4 (see vca_pack_weight_f32).
- * bias/in_scale/in_shift/in_alpha/res/stats may be NULL.  stats (2*Cout floats, zeroed by the
- * caller) receives per-output-channel sum and sum of squares of (y - bias) for a following
- * train-mode BatchNorm. */
+ * bias/in_scale/in_shift/in_alpha/res/stats may be NULL.  stats (zeroed by the caller) receives the
+ * per-output-channel sum and sum of squares of (y - bias) for a following train-mode BatchNorm, as
+ * VCA_CONV_STAT_SLOTS partial buffers of 2*Cout floats each (a workgroup adds to one of them; this fp32
+ * kernel and the stem only use the first, vca_conv_fwd_bf16 all); vca_bn_finalize_f32 totals them. */
+#define VCA_CONV_STAT_SLOTS 32
 int vca_conv_fwd_f32(const vca_conv_desc* d, const float* x, const float* wpack, const float* bias,
                      const float* in_scale, const float* in_shift, const float* in_alpha,
                      const float* res, float* y, float* stats, void* stream);
@@ -166,8 +168,10 @@ int vca_colstats_f32(int P, int C, const float* x, float* sums, void* stream);
 
 /* Train-mode statistics -> mean, 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale; updates the
  * running statistics in place (momentum, unbiased variance) when running_mean/var are given.
- * `sums` as written by vca_colstats_f32 or the convolution epilogue; `pivot` is what was subtracted (or NULL). */
-int vca_bn_finalize_f32(int C, float count, const float* sums, const float* pivot, const float* gamma,
+ * `sums`: nslots buffers of 2*C floats whose element-wise total is (sum, sum of squares) per channel: nslots = 1
+ * for the first 2*C floats written by vca_colstats_f32, VCA_CONV_STAT_SLOTS for the `stats` of a convolution
+ * epilogue; `pivot` is what was subtracted (or NULL). */
+int vca_bn_finalize_f32(int C, float count, const float* sums, int nslots, const float* pivot, const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                         float* mean, float* invstd, float* scale, float* shift, void* stream);
 

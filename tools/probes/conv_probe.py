@@ -18,7 +18,7 @@ w = torch.randn(Cout, Cin, K, K, device=dev) * 0.02
 pad = int(os.environ.get('PAD', K // 2))
 cfg = ops.ConvCfg(w.shape, x.shape, stride, (pad, pad), 0)
 gy = torch.randn(cfg.yshape, device=dev)
-stats = torch.zeros(2, Cout, device=dev) if os.environ.get('STATS') else None
+stats = torch.zeros(32, 2, Cout, device=dev) if os.environ.get('STATS') else None   # VCA_CONV_STAT_SLOTS buffers
 
 
 def run():

@@ -73,7 +73,7 @@ _SIGS = {
     'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     'vca_stem_patches_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_colstats_f32': ([_I, _I, _P, _P, _P], _I),
-    'vca_bn_finalize_f32': ([_I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    'vca_bn_finalize_f32': ([_I, _F, _P, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
     'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     'vca_affine_act_f32': ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P], _I),
     'vca_affine_act_bwd_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I, _P, _P, _P, _P], _I),

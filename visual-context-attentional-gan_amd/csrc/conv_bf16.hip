@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
   // halo image: .x = index of the pixel (of pixel (2*oy, 2*ox) for d2s), -1 for a row without output; .y = d2s only:
   // bit 0 / bit 1 set when row 2*oy + 1 / column 2*ox + 1 exists.
   int2* row_tab = reinterpret_cast<int2*>(smem);
+  float* stat_red = reinterpret_cast<float*>(smem + BM * sizeof(int2));   // [WM][BN][2], behind the row table
   if (tid < BM) {
     const int img = small_div(tid, inv_tpix), rem = tid - img * tpix;
     const int ty = small_div(rem, inv_tw), tx = rem - ty * a.TW;
@@ -378,10 +379,28 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
       s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (nv && lc == 0) {
-        atomicAdd(a.stats + n, s1);
-        atomicAdd(a.stats + d.Cout + n, s2);
+      if (lc == 0) {
+        stat_red[(wm * BN + wn * WTN + j * 16 + lr) * 2] = s1;
+        stat_red[(wm * BN + wn * WTN + j * 16 + lr) * 2 + 1] = s2;
       }
+    }
+  }
+  // Column statistics: the WM waves that share a column meet in LDS, then one pair of atomics per column and
+  // workgroup into one of VCA_CONV_STAT_SLOTS partial buffers (atomics on one address are resolved one after the
+  // other, ~10-20 ns each: thousands of workgroups adding to the 2*Cout addresses of a single buffer cost more than
+  // the convolution on the narrow layers)
+  if (a.stats) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < d.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WM; ++k) {
+        s1 += stat_red[(k * BN + tid) * 2];
+        s2 += stat_red[(k * BN + tid) * 2 + 1];
+      }
+      float* dst = a.stats + (size_t)(blockIdx.x % VCA_CONV_STAT_SLOTS) * 2 * d.Cout;
+      atomicAdd(dst + n0 + tid, s1);
+      atomicAdd(dst + d.Cout + n0 + tid, s2);
     }
   }
 }

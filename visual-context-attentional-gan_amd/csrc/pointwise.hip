@@ -96,15 +96,21 @@ __global__ __launch_bounds__(THR) void colstats_kernel(int P, int C, const float
 // ---------------------------------------------------------------------------------------------
 // finalize train-mode batch-norm statistics: mean / invstd / scale / shift, running-stat update
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(int C, float n, const float* __restrict__ sums, const float* __restrict__ pivot,
+__global__ void bn_finalize_kernel(int C, float n, const float* __restrict__ sums, int nslots,
+                                   const float* __restrict__ pivot,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float m1 = sums[c] / n;
-  float var = sums[C + c] / n - m1 * m1;
+  float t1 = sums[c], t2 = sums[C + c];
+  for (int k = 1; k < nslots; ++k) {   // partial buffers of a convolution epilogue
+    t1 += sums[(size_t)k * 2 * C + c];
+    t2 += sums[(size_t)k * 2 * C + C + c];
+  }
+  const float m1 = t1 / n;
+  float var = t2 / n - m1 * m1;
   var = var > 0.f ? var : 0.f;
   const float mean = m1 + (pivot ? pivot[c] : 0.f);
   const float invstd = rsqrtf(var + eps);
@@ -558,14 +564,14 @@ extern "C" int vca_colstats_f32(int P, int C, const float* x, float* sums, void*
   return vca_launch_status();
 }
 
-extern "C" int vca_bn_finalize_f32(int C, float count, const float* sums, const float* pivot, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                                   void* stream) {
-  VCA_CHECK_ARG(C > 0 && count > 0 && sums && mean && invstd && scale && shift);
+extern "C" int vca_bn_finalize_f32(int C, float count, const float* sums, int nslots, const float* pivot,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                   float* shift, void* stream) {
+  VCA_CHECK_ARG(C > 0 && count > 0 && sums && nslots >= 1 && mean && invstd && scale && shift);
   VCA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, count, sums,
-                     pivot, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     nslots, pivot, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   return vca_launch_status();
 }
 

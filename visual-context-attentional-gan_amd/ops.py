@@ -217,6 +217,7 @@ def _nsplit(backward=False):
 
 
 _ws_floats = {}   # (role, geometry) -> workspace floats of that launch
+CONV_STAT_SLOTS = 32   # VCA_CONV_STAT_SLOTS: partial buffers of the statistics a convolution epilogue produces
 
 
 def _split_ws(cfg, role, d, device):
@@ -430,7 +431,7 @@ class ConvStatsFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.save_for_backward(x, w)
-        stats = _zeros((2, cfg.cout), x.device)
+        stats = _zeros((CONV_STAT_SLOTS, 2, cfg.cout), x.device)
         y = _conv_fwd_raw(_c(x), w, bias, cfg, stats)
         ctx.mark_non_differentiable(stats)
         return y, stats
@@ -462,7 +463,7 @@ class ConvStatsSkipFn(torch.autograd.Function):
     def forward(ctx, x, w, cfg):
         ctx.cfg = cfg
         ctx.save_for_backward(x, w)
-        stats = _zeros((2, cfg.cout), x.device)
+        stats = _zeros((CONV_STAT_SLOTS, 2, cfg.cout), x.device)
         y = _conv_fwd_raw(_c(x), w, None, cfg, stats)
         ctx.mark_non_differentiable(stats)
         return y, stats, x.view_as(x)
@@ -784,7 +785,8 @@ def _bn_coef(x, bn, stats=None):
             sums = stats
         mom = bn.momentum if bn.momentum is not None else 0.1
         track = bn.training and bn.track_running_stats and bn.running_mean is not None
-        check(L.vca_bn_finalize_f32(C, float(P), ptr(sums), ptr(pivot), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+        nslots = sums.shape[0] if (stats is not None and sums.dim() == 3) else 1   # convolution epilogue: partial buffers
+        check(L.vca_bn_finalize_f32(C, float(P), ptr(sums), nslots, ptr(pivot), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                                     bn.eps, mom, ptr(bn.running_mean) if track else None,
                                     ptr(bn.running_var) if track else None,
                                     ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
@@ -823,7 +825,7 @@ def bn_act_parts(parts, bn, act=None):
         sums, pivot = torch.cat(sums, 1).contiguous(), torch.cat(pivots).contiguous()
         mom = bn.momentum if bn.momentum is not None else 0.1
         track = bn.training and bn.track_running_stats and bn.running_mean is not None
-        check(L.vca_bn_finalize_f32(C, float(n), ptr(sums), ptr(pivot), ptr(g.detach()), ptr(b.detach()), bn.eps, mom,
+        check(L.vca_bn_finalize_f32(C, float(n), ptr(sums), 1, ptr(pivot), ptr(g.detach()), ptr(b.detach()), bn.eps, mom,
                                     ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                                     ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
         if track:
