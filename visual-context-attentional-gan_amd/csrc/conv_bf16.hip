@@ -41,6 +41,7 @@ struct HArgs {
   int HWv;                        // halo positions per row that are actually staged (<= HW)
   int tiles_x, tiles_y, nsub;
   int vecA;
+  int vecY;    // y, res, bias and the split workspace are 16-byte aligned: the epilogue moves float4s
   int ksplit;  // >1: blockIdx.z owns a range of channel slices; its partial sums go to slab blockIdx.z of `part`
   float* part; //     (plain stores, folded into y by sum_slabs_kernel) or, without a workspace, into y with atomics
   unsigned part_stride;   // floats per slab
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if (NSPLIT == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
         }
       }
       wait_b();
@@ -328,60 +329,104 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
     row_tab[tid] = e;
   }
   __syncthreads();
+  // The MFMAs take the weight fragment as the row operand, so an accumulator tile is D[channel][pixel]: a lane holds
+  // 4 consecutive channels (4 * (lane >> 4) + r) of ONE pixel (lane & 15) and stores / adds them as one float4.
   const int cq = d.Cout >> 2;
   const int cmul = d.d2s_h ? cq : d.Cout;   // channels per pixel of the output tensor
-  size_t rbase[MT][4];
-  int rflag[MT][4];   // -1: no output
+  const bool vec = (cmul & 3) == 0 && a.vecY;   // groups of 4 channels stay inside a pixel (and a sub-pixel group)
+  size_t rbase[MT];
+  int rflag[MT];   // -1: no output
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int4 t0 = *reinterpret_cast<const int4*>(row_tab + wm * WTM + i * 16 + 4 * lc);
-    const int4 t1 = *reinterpret_cast<const int4*>(row_tab + wm * WTM + i * 16 + 4 * lc + 2);
-    const int px[4] = {t0.x, t0.z, t1.x, t1.z}, fl[4] = {t0.y, t0.w, t1.y, t1.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      rbase[i][r] = (size_t)max(px[r], 0) * cmul;
-      rflag[i][r] = px[r] < 0 ? -1 : fl[r];
-    }
+    const int2 e = row_tab[wm * WTM + i * 16 + lr];
+    rbase[i] = (size_t)max(e.x, 0) * cmul;
+    rflag[i] = e.x < 0 ? -1 : e.y;
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * WTN + j * 16 + lr;
-    const bool nv = n < d.Cout;
-    const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
-    const int grp = d.d2s_h ? n / cq : 0;
-    const int nc = n - grp * cq, ry = grp >> 1, rx = grp & 1;
-    const int need = d.d2s_h ? (ry | (rx << 1)) : 0;                 // neighbours the column's sub-pixel needs
-    const int coff = d.d2s_h ? (ry * d.d2s_w + rx) * cq + nc : n;    // offset of the column from the row's base
-    float s1 = 0.f, s2 = 0.f;
+    const int nb = n0 + wn * WTN + j * 16 + 4 * lc;   // first of this lane's 4 channels
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const bool nv = nb < d.Cout;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nv && a.bias && blockIdx.z == 0) b = *reinterpret_cast<const float4*>(a.bias + nb);
+      const int grp = d.d2s_h ? nb / cq : 0;
+      const int nc = nb - grp * cq, ry = grp >> 1, rx = grp & 1;
+      const int need = d.d2s_h ? (ry | (rx << 1)) : 0;                 // neighbours the channels' sub-pixel needs
+      const int coff = d.d2s_h ? (ry * d.d2s_w + rx) * cq + nc : nb;   // offset of the channels from the row's base
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MT; ++i) {
+        if (nv && rflag[i] >= 0) {
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (a.stats) {
+            s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+            s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
+          }
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          if ((rflag[i] & need) != need) continue;
+          const size_t o = rbase[i] + coff;
+          if (a.ksplit > 1) {
+            if (a.part) {
+              *reinterpret_cast<float4*>(a.part + (size_t)blockIdx.z * a.part_stride + o) = v;
+            } else {
+              atomicAdd(a.y + o, v.x); atomicAdd(a.y + o + 1, v.y);
+              atomicAdd(a.y + o + 2, v.z); atomicAdd(a.y + o + 3, v.w);
+            }
+          } else {
+            if (a.res) {
+              const float4 rr = *reinterpret_cast<const float4*>(a.res + o);
+              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            v.x *= d.out_scale; v.y *= d.out_scale; v.z *= d.out_scale; v.w *= d.out_scale;
+            *reinterpret_cast<float4*>(a.y + o) = v;
+          }
+        }
+      }
+    } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (nv && rflag[i][r] >= 0) {
-          float v = acc[i][j][r];
-          s1 += v;
-          s2 += v * v;
-          v += b;
-          if ((rflag[i][r] & need) != need) continue;
-          const size_t o = rbase[i][r] + coff;
-          if (a.ksplit > 1) {
-            if (a.part) a.part[(size_t)blockIdx.z * a.part_stride + o] = v;
-            else atomicAdd(a.y + o, v);
-          } else {
-            if (a.res) v += a.res[o];
-            a.y[o] = v * d.out_scale;
+        const int n = nb + r;
+        const bool nv = n < d.Cout;
+        const float b = (nv && a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+        const int grp = d.d2s_h ? n / cq : 0;
+        const int nc = n - grp * cq, ry = grp >> 1, rx = grp & 1;
+        const int need = d.d2s_h ? (ry | (rx << 1)) : 0;
+        const int coff = d.d2s_h ? (ry * d.d2s_w + rx) * cq + nc : n;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (nv && rflag[i] >= 0) {
+            float v = acc[i][j][r];
+            s1[r] += v;
+            s2[r] += v * v;
+            v += b;
+            if ((rflag[i] & need) != need) continue;
+            const size_t o = rbase[i] + coff;
+            if (a.ksplit > 1) {
+              if (a.part) a.part[(size_t)blockIdx.z * a.part_stride + o] = v;
+              else atomicAdd(a.y + o, v);
+            } else {
+              if (a.res) v += a.res[o];
+              a.y[o] = v * d.out_scale;
+            }
           }
         }
       }
     }
-    if (a.stats) {
-      s1 += __shfl_xor(s1, 16, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lc == 0) {
-        stat_red[(wm * BN + wn * WTN + j * 16 + lr) * 2] = s1;
-        stat_red[(wm * BN + wn * WTN + j * 16 + lr) * 2 + 1] = s2;
+    if (a.stats) {   // totals over the 16 pixels (lanes lr) of the tile rows, per channel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) {
+          s1[r] += __shfl_xor(s1[r], sh, 64);
+          s2[r] += __shfl_xor(s2[r], sh, 64);
+        }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          stat_red[(wm * BN + wn * WTN + j * 16 + 4 * lc + r) * 2] = s1[r];
+          stat_red[(wm * BN + wn * WTN + j * 16 + 4 * lc + r) * 2 + 1] = s2[r];
+        }
       }
     }
   }
@@ -452,7 +497,6 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAXSLOT = 5;  // distinct taps a wave's run of units can touch (<= 32 taps)
   constexpr int RRSLOT = 4;   // taps per wave when whole taps are dealt round-robin (17..32 taps)
-  const bool one_tap = false;
   const vca_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npos_total = a.NI * a.NPOS;
@@ -508,6 +552,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   // bias gradient: the workgroups of the first input-channel tile also sum the output-gradient values they stage
   const bool do_bias = a.bias_grad != nullptr && cit == 0;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // whole-tap schedule: halo offset of the (at most RRSLOT) taps wave, wave + 8, ... this wave owns
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int rr_tapoff[RRSLOT];
+#pragma unroll
+  for (int ts = 0; ts < RRSLOT; ++ts) {
+    const int tap = min(wave_u + 8 * ts, a.ntaps - 1);
+    const int kh = tap / d.KW;
+    rr_tapoff[ts] = kh * a.HW + tap - kh * d.KW;
+  }
 
   const int pt_beg = blockIdx.y * a.tiles_per_block;
   const int pt_end = min(a.ntiles, pt_beg + a.tiles_per_block);
@@ -621,28 +675,50 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
         bh[kk] = tr_read8(gy_hi + o0, gy_hi + o1);
         if (NSPLIT == 3) bl[kk] = tr_read8(gy_lo + o0, gy_lo + o1);
       }
-#pragma unroll
-      for (int ts = 0; ts < RRSLOT; ++ts) {
-        const int tap = one_tap ? 0 : wave + 8 * ts;
-        if (tap < a.ntaps && (!one_tap || ts == 0)) {
-          const int kh = tap / d.KW, kw = tap - kh * d.KW;
-          const int tapoff = kh * a.HW + kw;
+      if constexpr (NSPLIT == 1) {
+        // the input fragments of the next tap are requested before the MFMAs of the current one, so the LDS latency
+        // runs under them (a wave has the matrix pipe of its SIMD to itself for most of this phase)
+        auto load_a = [&](int ts, bf16x8 (&af)[4]) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const int ks = hf * 4 + kk;
-            if (one_tap && ks != wave) continue;   // 1-tap: the waves split the patch's pixels
-            const int p0 = pk[2 * ks] + tapoff, p1 = pk[2 * ks + 1] + tapoff;
+            const int p0 = pk[2 * ks] + rr_tapoff[ts], p1 = pk[2 * ks + 1] + rr_tapoff[ts];
+            const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
+            const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
+            af[kk] = tr_read8(halo_hi + o0, halo_hi + o1);
+          }
+        };
+        bf16x8 af[2][4];
+        if (wave_u < a.ntaps) load_a(0, af[0]);
+#pragma unroll
+        for (int ts = 0; ts < RRSLOT; ++ts) {
+          const int tap = wave_u + 8 * ts;
+          if (ts + 1 < RRSLOT && tap + 8 < a.ntaps) load_a(ts + 1, af[(ts + 1) & 1]);
+          if (tap < a.ntaps) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ts & 1][kk], bh[kk], acc[ts], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+      for (int ts = 0; ts < RRSLOT; ++ts) {
+        const int tap = wave_u + 8 * ts;
+        if (tap < a.ntaps) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int ks = hf * 4 + kk;
+            const int p0 = pk[2 * ks] + rr_tapoff[ts], p1 = pk[2 * ks + 1] + rr_tapoff[ts];
             const int o0 = p0 * 64 + ((colchunk ^ ((p0 >> 2) & 3)) << 4) + colbyte;
             const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
             const bf16x8 ah = tr_read8(halo_hi + o0, halo_hi + o1);
-            if (NSPLIT == 3) {
-              const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
-              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[ts], 0, 0, 0);
-              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[ts], 0, 0, 0);
-            }
+            const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
+            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[ts], 0, 0, 0);
+            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[ts], 0, 0, 0);
             acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc[ts], 0, 0, 0);
           }
         }
+      }
       }
     }
     } else {
@@ -695,8 +771,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
   const int co = co_base + lr;
 #pragma unroll
   for (int ts = 0; ts < RRSLOT; ++ts) {
-    const int tap = one_tap ? 0 : wave + 8 * ts;
-    if (tap < a.ntaps && (!one_tap || ts == 0) && co < d.Cout) {
+    const int tap = wave + 8 * ts;
+    if (tap < a.ntaps && co < d.Cout) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1675,6 +1751,8 @@ extern "C" int vca_conv_fwd_bf16_ws(const vca_conv_desc* d, int nsplit, const fl
   a.tiles_x = (d->OW + t.TW - 1) / t.TW;
   a.tiles_y = (d->OH + t.TH - 1) / t.TH;
   a.vecA = (d->Cin % 4 == 0) ? 1 : 0;
+  a.vecY = ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(res) | reinterpret_cast<size_t>(bias) |
+             reinterpret_cast<size_t>(ws)) & 15) == 0 ? 1 : 0;
   a.nsub = d->N * a.tiles_x * a.tiles_y;
   const int gx = (a.nsub + t.NI - 1) / t.NI;
   hipStream_t s = (hipStream_t)stream;

@@ -198,13 +198,23 @@ __global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int
     }
   }
   if (stats) {
+    // the workgroup's waves meet in LDS (the weight image is not needed any more): one atomic per statistic and
+    // workgroup instead of one per wave (atomics on one address are resolved one after the other)
+    float* red = reinterpret_cast<float*>(smem);   // [waves][2 * CO]
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float a = s1[j] + __shfl_xor(s1[j], 32, 64), c = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (lh == 0) {
-        atomicAdd(stats + j * 32 + lr, a);
-        atomicAdd(stats + CO + j * 32 + lr, c);
+        red[wave * 2 * CO + j * 32 + lr] = a;
+        red[wave * 2 * CO + CO + j * 32 + lr] = c;
       }
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      float t = 0.f;
+      for (int k = 0; k < NTHR / 64; ++k) t += red[k * 2 * CO + tid];
+      atomicAdd(stats + tid, t);
     }
   }
 }
