@@ -77,11 +77,11 @@ def roofline_probe(device, dtype):
     # `traffic_source` names the committed profile.  Algorithmic bytes (input + packed weights + output, each once)
     # are 98 + 26 + 98 = 222 MB; the excess is the input halo re-read once per 128-channel output block and the
     # weight stream re-read per pixel block, absorbed by the 256 MiB Infinity Cache.
-    traffic = (2 * 533930 + 102812) * 1024 if dtype in ('bf16x3', 'mixed') else None
+    traffic = (2 * 533887 + 98268) * 1024 if dtype in ('bf16x3', 'mixed') else None
     return dict(bound='mfma', kernel=kern + ' on decode.0.conv2', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
                 issued_frac=round(issued / peak, 4), traffic=traffic,
-                traffic_source='profiles/r2_decode0conv2_pmc_v2.txt (separate --pmc passes, not this run)'
+                traffic_source='profiles/r2_decode0conv2_pmc_v3.txt (separate --pmc passes, not this run)'
                 if traffic else None, launch_ms=round(dt * 1e3, 3), flops_per_launch=flops)
 
 
