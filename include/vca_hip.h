@@ -195,6 +195,16 @@ int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const 
                            const float* alpha, const float* res, const float* mean, const float* invstd, int act,
                            float slope, float oscale, int train, float* sums, float* gx, float* gres, void* stream);
 
+/* The same backward for a training step that accumulates in place (the reference's autograd adds the two branch
+ * gradients of a residual block, generator.py:128-130, and the parameter gradients, as separate passes):
+ *   gadd (may be NULL; needs gx): gx += gadd, the gradient arriving at x from its other consumer (identity shortcut);
+ *   gbeta_acc / ggamma_acc / galpha_acc (each may be NULL; need sums): the C-element d beta / d gamma / d alpha
+ *     totals are also added into these buffers (the parameters' gradient storage). */
+int vca_affine_act_bwd2_f32(int P, int C, const float* gy, const float* x, const float* scale, const float* shift,
+                            const float* alpha, const float* res, const float* mean, const float* invstd, int act,
+                            float slope, float oscale, int train, float* sums, float* gx, float* gres,
+                            const float* gadd, float* gbeta_acc, float* ggamma_acc, float* galpha_acc, void* stream);
+
 /* BatchNorm3d -> PReLU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the front-end (visual_front.py:12-14) without the
  * activated full-resolution map: writes the pooled map [N][OH][OW][C] and the argmax taps (0..8) straight from
  * x [N][H][W][C] and the batch-norm coefficients.  Backward: vca_maxpool3s2_bwd_f32, then vca_affine_act_bwd_f32. */

@@ -71,6 +71,63 @@ def test_bn_act(train, act, with_res):
 
 
 @gpu
+@pytest.mark.parametrize('act', ['prelu', 'leaky'])
+def test_bn_act_skip_alias_and_in_place_parameter_gradients(act):
+    """The training step's form of the same operator: x also feeds an identity shortcut taken from the alias output
+    (its gradient is added by the backward kernel), the parameter gradients are added into existing .grad storage by
+    the kernels (ops.direct_param_grad), num_batches_tracked is bumped when the step ends.  Run twice, so that the
+    gradients accumulate, against torch CPU autograd doing the same."""
+    from vcagan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 4, 9, 6, 128
+    x = torch.randn(N, H, W, C, generator=g) + 0.3
+    gy = torch.randn(N, H, W, C, generator=g)
+
+    def mk():
+        bn = nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(2)) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(3)))
+        a = nn.PReLU(C) if act == 'prelu' else None
+        if a is not None:
+            with torch.no_grad():
+                a.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(6)) * 0.5)
+        return bn.train(), a
+
+    bn_r, a_r = mk()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    for _ in range(2):
+        yr = bn_r(xr)
+        yr = F.leaky_relu(yr, 0.2) if a_r is None else a_r(yr)
+        ((yr * 0.7 + xr * 1.3) * gy.permute(0, 3, 1, 2)).sum().backward()
+
+    bn_d, a_d = mk()
+    bn_d.cuda()
+    params = [bn_d.weight, bn_d.bias]
+    if a_d is not None:
+        a_d.cuda()
+        params.append(a_d.weight)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    xd = x.cuda().requires_grad_(True)
+    dev = xd.device
+    for _ in range(2):
+        ops.step_begin(dev)
+        y, xa = ops.bn_act(xd, bn_d, ops.LEAKY if a_d is None else a_d, skip=True)
+        out = ((y * 0.7 + xa * 1.3) * gy.cuda()).sum()
+        with ops.direct_param_grad():
+            out.backward()
+        ops.step_end(dev)
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 1e-5
+    assert rel_err(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 2e-5
+    assert rel_err(bn_d.weight.grad, bn_r.weight.grad) < 2e-5
+    assert rel_err(bn_d.bias.grad, bn_r.bias.grad) < 2e-5
+    if a_d is not None:
+        assert rel_err(a_d.weight.grad, a_r.weight.grad) < 2e-5
+    assert int(bn_d.num_batches_tracked) == int(bn_r.num_batches_tracked) == 2
+
+
+@gpu
 def test_wide_and_1d_bn():
     from vcagan_amd import ops
     g = torch.Generator().manual_seed(9)

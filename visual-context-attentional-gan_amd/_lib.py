@@ -77,6 +77,7 @@ _SIGS = {
     'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     'vca_affine_act_f32': ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P], _I),
     'vca_affine_act_bwd_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I, _P, _P, _P, _P], _I),
+    'vca_affine_act_bwd2_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I] + [_P] * 8, _I),
     'vca_affine_act_pool3_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P], _I),
     'vca_pool2_f32': ([_I] * 7 + [_P, _P, _P], _I),
     'vca_leaky_pool2_fwd_f32': ([_I, _I, _I, _I, _F, _P, _P, _P, _P], _I),

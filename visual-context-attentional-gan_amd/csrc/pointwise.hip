@@ -44,13 +44,17 @@ __device__ __forceinline__ float act_grad(float z, int act, float slope) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// sums[0][.] += sums[1..BN_SLOTS)[.]
-__global__ void bn_fold_slots_kernel(int n, float* __restrict__ sums) {
+// sums[0][.] += sums[1..BN_SLOTS)[.]; n = rows * C.  Optionally row r of the total is also added into dst[r]
+// (the batch-norm backward hands its beta / gamma / PReLU-slope sums straight to the parameters' gradients).
+struct FoldDst { float* d[3]; };
+__global__ void bn_fold_slots_kernel(int n, float* __restrict__ sums, int C, FoldDst dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float t = sums[i];
   for (int k = 1; k < BN_SLOTS; ++k) t += sums[(size_t)k * n + i];
   sums[i] = t;
+  const int r = i / C;
+  if (r < 3 && dst.d[r]) dst.d[r][i - r * C] += t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,6 +196,7 @@ struct BwArgs {
   const float* mean; const float* invstd;
   float* sums;   // [3*C]
   float* gx; float* gres;
+  const float* gadd;   // optional: added to gx (the gradient of a second consumer of x)
 };
 
 __device__ __forceinline__ void bw_point(const BwArgs& a, size_t i, int col, float gz[4], float xh[4], float zneg[4],
@@ -270,6 +275,9 @@ __global__ __launch_bounds__(THR) void bn_act_bwd_reduce_kernel(BwArgs a) {
   }
 }
 
+// GADD: a.gadd is present.  A template parameter, not a run-time test: the test inside the loop cost the launches
+// without it a third of their speed.
+template <bool GADD>
 __global__ __launch_bounds__(THR) void bn_act_bwd_apply_kernel(BwArgs a) {
   const int C4 = a.C >> 2;
   const size_t total = (size_t)a.P * C4;
@@ -290,6 +298,10 @@ __global__ __launch_bounds__(THR) void bn_act_bwd_apply_kernel(BwArgs a) {
       if (a.scale) {
         const float4 sc = ld4(a.scale + col);
         o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
+      }
+      if (GADD) {
+        const float4 e = ld4(a.gadd + i * 4);
+        o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
       }
       st4(a.gx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
@@ -560,7 +572,8 @@ extern "C" int vca_colstats_f32(int P, int C, const float* x, float* sums, void*
   int g = (P + TY - 1) / TY;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(colstats_kernel, dim3(g), dim3(THR), 0, (hipStream_t)stream, P, C, x, sums);
-  hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, 2 * C, sums);
+  hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, 2 * C, sums,
+                     C, FoldDst{{nullptr, nullptr, nullptr}});
   return vca_launch_status();
 }
 
@@ -595,27 +608,44 @@ extern "C" int vca_affine_act_f32(int P, int C, const float* x, const float* sca
   return vca_launch_status();
 }
 
-extern "C" int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const float* scale,
-                                      const float* shift, const float* alpha, const float* res, const float* mean,
-                                      const float* invstd, int act, float slope, float oscale, int train,
-                                      float* sums, float* gx, float* gres, void* stream) {
+extern "C" int vca_affine_act_bwd2_f32(int P, int C, const float* gy, const float* x, const float* scale,
+                                       const float* shift, const float* alpha, const float* res, const float* mean,
+                                       const float* invstd, int act, float slope, float oscale, int train,
+                                       float* sums, float* gx, float* gres, const float* gadd, float* gbeta_acc,
+                                       float* ggamma_acc, float* galpha_acc, void* stream) {
   VCA_CHECK_ARG(P > 0 && C > 0 && (C % 4) == 0 && gy && x && act >= 0 && act <= 4);
   VCA_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (mean == nullptr) == (invstd == nullptr));
   VCA_CHECK_ARG(act != VCA_ACT_PRELU || alpha);
   VCA_CHECK_ARG(!train || (sums && mean && scale));
   VCA_CHECK_ARG(act != VCA_ACT_PRELU || sums);
-  BwArgs a{P, C, act, train, slope, oscale, 1.0f / (float)P, gy, x, scale, shift, alpha, res, mean, invstd, sums, gx, gres};
+  VCA_CHECK_ARG(!gadd || gx);
+  VCA_CHECK_ARG(sums || !(gbeta_acc || ggamma_acc || galpha_acc));
+  VCA_CHECK_ARG(!galpha_acc || act == VCA_ACT_PRELU);
+  BwArgs a{P, C, act, train, slope, oscale, 1.0f / (float)P, gy, x, scale, shift, alpha, res, mean, invstd, sums, gx, gres,
+           gadd};
   hipStream_t s = (hipStream_t)stream;
   if (sums) {
     const int C4 = C / 4, TX = C4 < THR ? C4 : THR, TY = THR / TX;
     int g = (P + TY - 1) / TY;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(g), dim3(THR), 0, s, a);
-    hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((3 * C + 127) / 128), dim3(128), 0, s, 3 * C, sums);
+    hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((3 * C + 127) / 128), dim3(128), 0, s, 3 * C, sums, C,
+                       FoldDst{{gbeta_acc, ggamma_acc, galpha_acc}});
   }
-  if (gx || gres)
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 4))), dim3(THR), 0, s, a);
+  if (gx || gres) {
+    const dim3 grid(grid_for((size_t)P * (C / 4)));
+    if (gadd) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(THR), 0, s, a);
+    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(THR), 0, s, a);
+  }
   return vca_launch_status();
+}
+
+extern "C" int vca_affine_act_bwd_f32(int P, int C, const float* gy, const float* x, const float* scale,
+                                      const float* shift, const float* alpha, const float* res, const float* mean,
+                                      const float* invstd, int act, float slope, float oscale, int train,
+                                      float* sums, float* gx, float* gres, void* stream) {
+  return vca_affine_act_bwd2_f32(P, C, gy, x, scale, shift, alpha, res, mean, invstd, act, slope, oscale, train, sums,
+                                 gx, gres, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int vca_pool2_f32(int mode, int N, int Hs, int Ws, int Hl, int Wl, int C, const float* x, float* y,

@@ -117,7 +117,13 @@ class GenResBlk(nn.Module):
             # the block input feeds the shortcut convolution and the batch-norm branch: taking the latter from the
             # convolution's alias output lets its input-gradient kernel add the branch's gradient in its epilogue
             s, _, x = ops.conv2d_skip(x, self.conv1x1.weight, 1, 0)
-        r, st = _conv(ops.bn_act(x, self.norm1, ops.LEAKY), self.conv1, ups, want_stats=True)   # nearest x2 read inside the conv
+        if not self.learned_sc:
+            # identity shortcut: taken from the batch-norm node's alias output, whose backward kernel then adds the
+            # shortcut's gradient while it writes the branch's
+            a, x = ops.bn_act(x, self.norm1, ops.LEAKY, skip=True)
+        else:
+            a = ops.bn_act(x, self.norm1, ops.LEAKY)
+        r, st = _conv(a, self.conv1, ups, want_stats=True)   # nearest x2 read inside the conv
         r = _conv(ops.bn_act(r, self.norm2, ops.LEAKY, stats=st), self.conv2)
         if s is None:
             if self.learned_sc:
@@ -232,9 +238,15 @@ class Decoder(nn.Module):
         self.g3.extend([GenResBlk(64, 32, upsample=True), GenResBlk(32, 32), GenResBlk(32, 32)])
 
     @staticmethod
-    def _mel(head, h):
-        y = _conv(ops.bn_act(h, head[0], ops.LEAKY), head[2])          # (B, F, T, 1)
-        return ops.tanh(y).view(y.shape[0], 1, y.shape[1], y.shape[2])
+    def _mel(head, h, skip=False):
+        """to_mel head; skip=True also returns an alias of h for its other consumers (their gradients then arrive at
+        the batch-norm node and are added by its backward kernel)."""
+        a = ops.bn_act(h, head[0], ops.LEAKY, skip=skip)
+        if skip:
+            a, h = a
+        y = _conv(a, head[2])                                           # (B, F, T, 1)
+        y = ops.tanh(y).view(y.shape[0], 1, y.shape[1], y.shape[2])
+        return (y, h) if skip else y
 
     def forward(self, s, x, len, noise=None):
         """s: (B, 512, T) sentence features; x: (B, T, 512) phonemes; len: valid frames per clip.
@@ -259,15 +271,15 @@ class Decoder(nn.Module):
             h = block(h)
         for block in self.g1:
             h = block(h)
-        g1 = h
-        h = _conv(ops.concat2(h, self.att1(ctx, g1, len), B, h.shape[1], h.shape[2]), self.attconv1)
+        m1, h = self._mel(self.to_mel1, h, skip=True)
+        h = _conv(ops.concat2(h, self.att1(ctx, h, len), B, h.shape[1], h.shape[2]), self.attconv1)
         for block in self.g2:
             h = block(h)
-        g2 = h
-        h = _conv(ops.concat2(h, self.att2(ctx, g2, len), B, h.shape[1], h.shape[2]), self.attconv2)
+        m2, h = self._mel(self.to_mel2, h, skip=True)
+        h = _conv(ops.concat2(h, self.att2(ctx, h, len), B, h.shape[1], h.shape[2]), self.attconv2)
         for block in self.g3:
             h = block(h)
-        return self._mel(self.to_mel1, g1), self._mel(self.to_mel2, g2), self._mel(self.to_mel3, h)
+        return m1, m2, self._mel(self.to_mel3, h)
 
 
 class Discriminator(nn.Module):

@@ -30,23 +30,24 @@ _pack_cache = {}     # id(parameter) -> (weakref, {mode: (version, packed tensor
 
 # Small zero-initialised scratch (batch-norm partial sums, convolution statistics): inside a training step they are
 # carved from one arena that a single fill clears at the start of the step, instead of one fill launch each.
-_arena = {}          # device -> [buffer, offset, active, used by the previous step]
-_ARENA_FLOATS = 8 << 20
+_arena = {}          # device -> [buffer, offset, active, used by the previous steps, length cleared for this step]
+_ARENA_FLOATS = 16 << 20
+_nbt_pending = {}    # device -> {id(counter): [counter tensor, increments]}: batch-norm step counters bumped at step_end
 
 
 def step_begin(device):
-    """Start of a training step: clear the part of the scratch arena the previous step used and hand it out again."""
+    """Start of a training step: clear the part of the scratch arena the previous steps used and hand it out again.
+    Inside the step only the cleared part is handed out (a request beyond it gets its own zero fill), so a captured
+    step, whose fill length is frozen into the graph, stays correct whatever it carves out; after one eager step of
+    the same shapes (GraphedStep insists on one) the cleared part covers everything."""
     a = _arena.get(device)
     if a is None:
-        a = _arena[device] = [torch.zeros(_ARENA_FLOATS, device=device, dtype=torch.float32), 0, False, 0]
+        a = _arena[device] = [torch.zeros(_ARENA_FLOATS, device=device, dtype=torch.float32), 0, False, 0, 0]
+    _flush_nbt(device)
     a[3] = max(a[3], a[1])
-    if torch.cuda.is_current_stream_capturing():
-        # the fill length is frozen into the graph: it must cover whatever the captured step carves out, and that
-        # is only known once the step has run, so clear the whole arena (32 MiB, ~10 us)
-        a[0].zero_()
-    elif a[3]:
-        a[0][:a[3]].zero_()
-    a[1], a[2] = 0, True
+    n = min(_ARENA_FLOATS, (a[3] + (1 << 18)) if a[3] else _ARENA_FLOATS)   # slack: a step may carve a little more
+    a[0][:n].zero_()
+    a[1], a[2], a[4] = 0, True, n
 
 
 def step_end(device):
@@ -54,6 +55,7 @@ def step_end(device):
     if a is not None:
         a[3] = max(a[3], a[1])
         a[2] = False
+    _flush_nbt(device)
 
 
 def _zeros(shape, device):
@@ -62,11 +64,39 @@ def _zeros(shape, device):
     n = 1
     for d in shape:
         n *= d
-    if a is not None and a[2] and a[1] + n <= _ARENA_FLOATS:
+    if a is not None and a[2]:
         off = a[1]
-        a[1] = off + (n + 63) // 64 * 64
-        return a[0][off:off + n].view(shape)
+        a[1] = off + (n + 63) // 64 * 64      # counted even when it does not fit, so the next step clears enough
+        if off + n <= a[4]:
+            return a[0][off:off + n].view(shape)
     return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+def _bump_nbt(bn):
+    """num_batches_tracked += 1 (nn.BatchNorm's train-mode forward).  Inside a training step the increments of all
+    batch-norm layers are collected and applied by one multi-tensor launch when the step ends."""
+    t = bn.num_batches_tracked
+    a = _arena.get(t.device)
+    if a is not None and a[2]:
+        ent = _nbt_pending.setdefault(t.device, {})
+        e = ent.get(id(t))
+        if e is None:
+            ent[id(t)] = [t, 1]
+        else:
+            e[1] += 1
+    else:
+        t += 1
+
+
+def _flush_nbt(device):
+    ent = _nbt_pending.pop(device, None)
+    if not ent:
+        return
+    by_count = {}
+    for t, k in ent.values():
+        by_count.setdefault(k, []).append(t)
+    for k, ts in by_count.items():
+        torch._foreach_add_(ts, k)
 
 
 def _wkey(w):
@@ -434,6 +464,7 @@ class ConvStatsFn(torch.autograd.Function):
         stats = _zeros((CONV_STAT_SLOTS, 2, cfg.cout), x.device)
         y = _conv_fwd_raw(_c(x), w, bias, cfg, stats)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)    # no zero-filled gradient tensor for the statistics output
         return y, stats
 
     @staticmethod
@@ -466,6 +497,7 @@ class ConvStatsSkipFn(torch.autograd.Function):
         stats = _zeros((CONV_STAT_SLOTS, 2, cfg.cout), x.device)
         y = _conv_fwd_raw(_c(x), w, None, cfg, stats)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats, x.view_as(x)
 
     @staticmethod
@@ -667,6 +699,7 @@ class StemConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfg = cfg
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
@@ -728,12 +761,34 @@ def _pc(x):
     return x.numel() // c, c
 
 
+def _bn_param_sinks(ctx_params, coef, act, want_alpha):
+    """Gradient storage of (beta, gamma, alpha) when the step accumulates in place: the backward kernels then add the
+    per-channel totals there themselves and autograd gets None (no accumulate launch per parameter).  All or nothing."""
+    gamma, beta, alpha = ctx_params
+    need = []
+    if coef is not None:
+        need += [beta, gamma]
+    if act == ACT_PRELU and want_alpha:
+        need.append(alpha)
+    if not need or any(p is None for p in need):
+        return None
+    sinks = [_grad_sink(p) for p in need]
+    if any(t is None for t in sinks):
+        return None
+    sb, sg = (sinks[0], sinks[1]) if coef is not None else (None, None)
+    sa = sinks[-1] if (act == ACT_PRELU and want_alpha) else None
+    return sb, sg, sa
+
+
 class BnActFn(torch.autograd.Function):
     """y = act(x*scale + shift + res) * oscale with (scale, shift) from batch-norm coefficients `coef`
-    (rows: mean, invstd, scale, shift) or absent; gradients for x, gamma, beta, alpha, res."""
+    (rows: mean, invstd, scale, shift) or absent; gradients for x, gamma, beta, alpha, res.
+    With skip=True the input is handed back as a second (alias) output: a block whose input also feeds an identity
+    shortcut (generator.py:128-130) takes the shortcut from it, so autograd delivers the shortcut's gradient to this
+    node and the backward kernel adds it while writing gx, instead of a full-size add afterwards."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, alpha, res, coef, act, slope, oscale, train):
+    def forward(ctx, x, gamma, beta, alpha, res, coef, act, slope, oscale, train, skip=False):
         x = _c(x)
         res = _c(res) if res is not None else None
         P, C = _pc(x)
@@ -743,27 +798,41 @@ class BnActFn(torch.autograd.Function):
                                             ptr(y), stream()), 'affine_act')
         ctx.save_for_backward(x, alpha, res, coef)
         ctx.cfg = (act, slope, oscale, train, gamma is not None, beta is not None)
+        ctx.params = (gamma, beta, alpha)
+        ctx.set_materialize_grads(False)
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
     @once
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, alpha, res, coef = ctx.saved_tensors
         act, slope, oscale, train, has_g, has_b = ctx.cfg
+        if gy is None:                       # only the alias output was used
+            return gskip, None, None, None, None, None, None, None, None, None, None
         P, C = _pc(x)
         gy = _c(gy)
         need_sums = coef is not None or act == ACT_PRELU
         sums = _zeros((16, 3, C), x.device) if need_sums else None   # VCA_BN_SLOTS
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_gx = ctx.needs_input_grad[0]
+        gx = torch.empty_like(x) if want_gx else None
         gres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[4]) else None
         mean, invstd, sc, sh = (coef[0], coef[1], coef[2], coef[3]) if coef is not None else (None,) * 4
-        check(_lib.lib().vca_affine_act_bwd_f32(P, C, ptr(gy), ptr(x), ptr(sc), ptr(sh), ptr(alpha), ptr(res),
-                                                ptr(mean), ptr(invstd), act, slope, oscale, 1 if train else 0,
-                                                ptr(sums), ptr(gx), ptr(gres), stream()), 'affine_act_bwd')
-        ggamma = sums[0, 1] if (coef is not None and has_g) else None
-        gbeta = sums[0, 0] if (coef is not None and has_b) else None
-        galpha = sums[0, 2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
-        return gx, ggamma, gbeta, galpha, gres, None, None, None, None, None
+        sinks = _bn_param_sinks(ctx.params, coef, act, ctx.needs_input_grad[3]) if (need_sums and has_g == has_b) else None
+        sb, sg, sa = sinks if sinks is not None else (None, None, None)
+        gadd = _c(gskip) if (gskip is not None and want_gx) else None
+        check(_lib.lib().vca_affine_act_bwd2_f32(P, C, ptr(gy), ptr(x), ptr(sc), ptr(sh), ptr(alpha), ptr(res),
+                                                 ptr(mean), ptr(invstd), act, slope, oscale, 1 if train else 0,
+                                                 ptr(sums), ptr(gx), ptr(gres), ptr(gadd), ptr(sb), ptr(sg), ptr(sa),
+                                                 stream()), 'affine_act_bwd')
+        if sinks is not None:
+            ggamma = gbeta = galpha = None
+        else:
+            ggamma = sums[0, 1] if (coef is not None and has_g) else None
+            gbeta = sums[0, 0] if (coef is not None and has_b) else None
+            galpha = sums[0, 2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
+        return gx, ggamma, gbeta, galpha, gres, None, None, None, None, None, None
 
 
 def _bn_coef(x, bn, stats=None):
@@ -791,7 +860,7 @@ def _bn_coef(x, bn, stats=None):
                                     ptr(bn.running_var) if track else None,
                                     ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
         if track:
-            bn.num_batches_tracked += 1
+            _bump_nbt(bn)
         return coef, True
     check(L.vca_bn_eval_coeff_f32(C, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.weight.detach()),
                                   ptr(bn.bias.detach()), bn.eps, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
@@ -829,7 +898,7 @@ def bn_act_parts(parts, bn, act=None):
                                     ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                                     ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream()), 'bn_finalize')
         if track:
-            bn.num_batches_tracked += 1
+            _bump_nbt(bn)
         train = True
     else:
         check(L.vca_bn_eval_coeff_f32(C, ptr(bn.running_mean), ptr(bn.running_var), ptr(g.detach()), ptr(b.detach()),
@@ -878,11 +947,12 @@ def hband_expand(p, H, K=1, pad=0, base=None):
     return HBandExpandFn.apply(p, base, H, K, pad)
 
 
-def bn_act(x, bn, act=None, residual=None, stats=None):
-    """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor."""
+def bn_act(x, bn, act=None, residual=None, stats=None, skip=False):
+    """act(batch_norm(x) + residual) over the last (channel) axis of a channels-last tensor.  skip=True: returns
+    (y, alias of x) for a block whose input also feeds an identity shortcut (see BnActFn)."""
     code, slope, alpha = _act_code(act)
     coef, train = _bn_coef(x, bn, stats)
-    return BnActFn.apply(x, bn.weight, bn.bias, alpha, residual, coef, code, slope, 1.0, train)
+    return BnActFn.apply(x, bn.weight, bn.bias, alpha, residual, coef, code, slope, 1.0, train, skip)
 
 
 class ActFn(torch.autograd.Function):
@@ -1116,6 +1186,7 @@ class BnActPool3Fn(torch.autograd.Function):
                                                       slope, ptr(y), idx.data_ptr(), stream()), 'affine_act_pool3')
         ctx.save_for_backward(x, alpha, coef, idx)
         ctx.cfg = (act, slope, train)
+        ctx.params = (gamma, beta, alpha)
         return y
 
     @staticmethod
@@ -1129,11 +1200,16 @@ class BnActPool3Fn(torch.autograd.Function):
         check(L.vca_maxpool3s2_bwd_f32(n, h, w, c, ptr(_c(gy)), idx.data_ptr(), ptr(g), stream()), 'maxpool_bwd')
         sums = _zeros((16, 3, c), x.device)   # VCA_BN_SLOTS
         gx = torch.empty_like(x)
-        check(L.vca_affine_act_bwd_f32(n * h * w, c, ptr(g), ptr(x), ptr(coef[2]), ptr(coef[3]), ptr(alpha), None,
-                                       ptr(coef[0]), ptr(coef[1]), act, slope, 1.0, 1 if train else 0, ptr(sums),
-                                       ptr(gx), None, stream()), 'affine_act_bwd')
+        sinks = _bn_param_sinks(ctx.params, coef, act, ctx.needs_input_grad[3])
+        sb, sg, sa = sinks if sinks is not None else (None, None, None)
+        check(L.vca_affine_act_bwd2_f32(n * h * w, c, ptr(g), ptr(x), ptr(coef[2]), ptr(coef[3]), ptr(alpha), None,
+                                        ptr(coef[0]), ptr(coef[1]), act, slope, 1.0, 1 if train else 0, ptr(sums),
+                                        ptr(gx), None, None, ptr(sb), ptr(sg), ptr(sa), stream()), 'affine_act_bwd')
+        gx = gx if ctx.needs_input_grad[0] else None
+        if sinks is not None:
+            return gx, None, None, None, None, None, None, None
         galpha = sums[0, 2] if (act == ACT_PRELU and ctx.needs_input_grad[3]) else None
-        return (gx if ctx.needs_input_grad[0] else None), sums[0, 1], sums[0, 0], galpha, None, None, None, None
+        return gx, sums[0, 1], sums[0, 0], galpha, None, None, None, None
 
 
 def bn_act_maxpool3(x, bn, act=None, stats=None):
@@ -1476,6 +1552,19 @@ def _gemm_tn(x2d, gy2d, w):
     return _conv_wgrad_raw(x2d, gy2d, _lin_cfg(w, x2d.shape[0]))
 
 
+def _lin_wgrad(x2d, gy2d, w, b):
+    """Gradients (gw, gb) of y = x @ w^T + b; None where a gradient was added straight into the parameter's gradient
+    storage (direct_param_grad)."""
+    cfg = _lin_cfg(w, x2d.shape[0])
+    bsink = _grad_sink(b)
+    _bias_done[0] = False
+    gw = _conv_wgrad_raw(x2d, gy2d, cfg, _grad_sink(w), bsink)
+    gb = None
+    if not (bsink is not None and _bias_done[0]):
+        gb = _bias_grad(gy2d, b, cfg.cout)
+    return gw, gb
+
+
 def _rec_gemm(xs, ws, biases, mode):
     """The recurrent products of the two directions of a layer in one launch: y_i = x_i @ W_i^T + b_i (mode 0) or
     y_i = x_i @ W_i (mode 1, the input gradient).  Exact-fp32 precision falls back to the general GEMM path."""
@@ -1587,8 +1676,9 @@ class GruLayerFn(torch.autograd.Function):
         for d in range(2):
             w_ih = wts[4 * d]
             gi2, gh2 = d_gi[d].view(T * B, 3 * H), d_gh[d].view(T * B, 3 * H)
-            grads += [_gemm_tn(x2, gi2, w_ih), _gemm_tn(hprev[d].view(T * B, H), gh2, w_hh[d]), colsum(gi2, 3 * H),
-                      colsum(gh2, 3 * H)]
+            gw_ih, gb_ih = _lin_wgrad(x2, gi2, w_ih, wts[4 * d + 2])
+            gw_hh, gb_hh = _lin_wgrad(hprev[d].view(T * B, H), gh2, w_hh[d], wts[4 * d + 3])
+            grads += [gw_ih, gw_hh, gb_ih, gb_hh]
             if ctx.needs_input_grad[0]:
                 part = _gemm_nn(gi2, w_ih)
                 dx = part if dx is None else dx + part
