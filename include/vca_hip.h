@@ -301,6 +301,21 @@ int vca_softplus_bwd_f32(int n, const float* x, float sign, float scale, const f
 int vca_l1_sum_f32(long long n, const float* a, const float* b, float scale, float* out, void* stream);
 int vca_l1_bwd_f32(long long n, const float* a, const float* b, float scale, const float* gout, float* ga,
                    void* stream);
+/* Connectionist temporal classification loss on frame logits [B][T][V] (log-softmax over V inside), the auxiliary
+ * text loss of the LRS3 multi-task configuration.  The reference ships the ASR scorer only for inference
+ * (ASR_model/GRID/test.py:160-193 decodes its logits greedily; alphabet and blank '_' = 0 from
+ * ASR_model/GRID/src/data/vid_aud_GRID_test.py:20-33), so the loss follows torch.nn.functional.ctc_loss
+ * (reduction 'none'), which the tests compare it with.  targets [B][Lmax] int32 class ids, in_len / tgt_len [B] int32.
+ * fwd: nll[b] = -log p(targets_b | logits_b); alpha_ws receives B*T*(2*Lmax+1) doubles (log alpha) for the backward
+ * call.  zero_infinity != 0: an impossible alignment gives loss 0 and gradient 0 instead of inf / NaN.
+ * bwd: glogits[b][t][v] = gnll[b] * d nll[b] / d logits[b][t][v], zero for t >= in_len[b].
+ * Limits: T <= 2048, V <= 64, Lmax <= 511. */
+int vca_ctc_loss_fwd_f32(int B, int T, int V, int Lmax, const float* logits, const int* targets, const int* in_len,
+                         const int* tgt_len, int blank, int zero_infinity, double* alpha_ws, float* nll, void* stream);
+int vca_ctc_loss_bwd_f32(int B, int T, int V, int Lmax, const float* logits, const int* targets, const int* in_len,
+                         const int* tgt_len, int blank, int zero_infinity, const double* alpha_ws, const float* nll,
+                         const float* gnll, float* glogits, void* stream);
+
 /* All loss heads of one phase of the step in one launch (train.py:200-205 discriminator terms incl. the R1 squared
  * norms of :188-194, :222-231 generator terms).  Head e computes v_e = scale * sum_i f(x_i[, y_i]) with
  * f = softplus(sign*x) [kind 0, generator.py:363-366], |x - y| [1, nn.L1Loss], x^2 [2], x [3] and adds weight[k] * v_e

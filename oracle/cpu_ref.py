@@ -363,8 +363,13 @@ def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
     return g, d
 
 
-def gan_step(models, optimizers, batch, variant='grid', noise=None):
+def gan_step(models, optimizers, batch, variant='grid', noise=None, ctc=None):
     """One full G+D step.  batch = dict(mel (B,1,80,4T), spec (B,1,321,4T), vid (B,1,T,H,W), vid_len).
+
+    ctc: None or dict(front, back, weight): the multi-task extension (no counterpart in the reference's training
+    scripts; its ASR scorer, ASR_model/GRID/src/models, is used frozen and in eval mode): gen_loss gains
+    weight * F.ctc_loss(log_softmax(back(front(g3))), batch['text'], vid_len, batch['text_len'], blank=0,
+    reduction='mean', zero_infinity=True).
 
     Returns a dict of python floats plus the generator outputs (detached).
     """
@@ -414,12 +419,22 @@ def gan_step(models, optimizers, batch, variant='grid', noise=None):
         g_loss = g_adv
         recon = sum(F.l1_loss(g, t) for g, t in zip((g1, g2, g3), tgt)) / 3 + F.l1_loss(gs, spec)
         gen_loss = g_loss + 50.0 * recon + g_sync
+    ctc_loss = None
+    if ctc is not None:
+        lp = F.log_softmax(ctc['back'](ctc['front'](g3)), 2).transpose(0, 1)          # (T, B, 28)
+        frames = torch.as_tensor([int(v) for v in vid_len]).clamp(max=lp.size(0))
+        ctc_loss = F.ctc_loss(lp, batch['text'], frames, torch.as_tensor(batch['text_len']), blank=0,
+                              reduction='mean', zero_infinity=True)
+        gen_loss = gen_loss + float(ctc['weight']) * ctc_loss
     for n in D_NAMES + ('gen', 'post'):
         m[n].zero_grad()
     gen_loss.backward()
     g_opt.step()
     f = lambda t: t.detach().item()
-    return dict(dis_loss=f(dis_loss), gen_loss=f(gen_loss), sync_loss=f(sync_loss),
-                g_sync_loss=f(g_sync), recon_loss=f(recon), g_loss=f(g_loss),
-                grad_p=[f(x) for x in r1],
-                g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+    out = dict(dis_loss=f(dis_loss), gen_loss=f(gen_loss), sync_loss=f(sync_loss),
+               g_sync_loss=f(g_sync), recon_loss=f(recon), g_loss=f(g_loss),
+               grad_p=[f(x) for x in r1],
+               g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+    if ctc_loss is not None:
+        out['ctc_loss'] = f(ctc_loss)
+    return out

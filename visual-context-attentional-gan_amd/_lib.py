@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
-           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip')
+           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip')
 
 
 def build(force=False, verbose=False):
@@ -77,6 +77,8 @@ _SIGS = {
     'vca_bn_eval_coeff_f32': ([_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     'vca_affine_act_f32': ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P], _I),
     'vca_affine_act_bwd_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I, _P, _P, _P, _P], _I),
+    'vca_ctc_loss_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P], _I),
+    'vca_ctc_loss_bwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P], _I),
     'vca_affine_act_bwd2_f32': ([_I, _I] + [_P] * 8 + [_I, _F, _F, _I] + [_P] * 8, _I),
     'vca_affine_act_pool3_fwd_f32': ([_I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P], _I),
     'vca_pool2_f32': ([_I] * 7 + [_P, _P, _P], _I),

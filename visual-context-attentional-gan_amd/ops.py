@@ -1676,9 +1676,12 @@ class GruLayerFn(torch.autograd.Function):
         for d in range(2):
             w_ih = wts[4 * d]
             gi2, gh2 = d_gi[d].view(T * B, 3 * H), d_gh[d].view(T * B, 3 * H)
-            gw_ih, gb_ih = _lin_wgrad(x2, gi2, w_ih, wts[4 * d + 2])
-            gw_hh, gb_hh = _lin_wgrad(hprev[d].view(T * B, H), gh2, w_hh[d], wts[4 * d + 3])
-            grads += [gw_ih, gw_hh, gb_ih, gb_hh]
+            if any(ctx.needs_input_grad[1 + 4 * d:5 + 4 * d]):
+                gw_ih, gb_ih = _lin_wgrad(x2, gi2, w_ih, wts[4 * d + 2])
+                gw_hh, gb_hh = _lin_wgrad(hprev[d].view(T * B, H), gh2, w_hh[d], wts[4 * d + 3])
+                grads += [gw_ih, gw_hh, gb_ih, gb_hh]
+            else:                              # frozen weights (the ASR scorer under the CTC loss)
+                grads += [None] * 4
             if ctx.needs_input_grad[0]:
                 part = _gemm_nn(gi2, w_ih)
                 dx = part if dx is None else dx + part
@@ -1799,6 +1802,48 @@ def sync_loss(v_feat, a_feat, temp, gen):
     if gen:
         return SyncCosFn.apply(v_feat, a_feat)
     return SyncNceFn.apply(v_feat, a_feat, temp)
+
+
+class CtcNllFn(torch.autograd.Function):
+    """Per-sample CTC negative log-likelihood of frame logits (B, T, V), log-softmax over V included; the semantics of
+    torch.nn.functional.ctc_loss(log_softmax(logits), ..., reduction='none').  Gradient for the logits only."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, in_len, tgt_len, blank, zero_infinity):
+        logits = _c(logits)
+        B, T, V = logits.shape
+        dev = logits.device
+        targets, in_len, tgt_len = (_c(t.to(device=dev, dtype=torch.int32)) for t in (targets, in_len, tgt_len))
+        assert targets.dim() == 2 and targets.shape[0] == B and in_len.shape == (B,) and tgt_len.shape == (B,)
+        Lmax = targets.shape[1]
+        alpha = torch.empty((B, T, 2 * Lmax + 1), device=dev, dtype=torch.float64)
+        nll = torch.empty((B,), device=dev, dtype=torch.float32)
+        check(_lib.lib().vca_ctc_loss_fwd_f32(B, T, V, Lmax, ptr(logits), targets.data_ptr(), in_len.data_ptr(),
+                                              tgt_len.data_ptr(), blank, 1 if zero_infinity else 0,
+                                              alpha.data_ptr(), ptr(nll), stream()), 'ctc_loss_fwd')
+        ctx.save_for_backward(logits, targets, in_len, tgt_len, alpha, nll)
+        ctx.cfg = (blank, zero_infinity)
+        return nll
+
+    @staticmethod
+    @once
+    def backward(ctx, gnll):
+        logits, targets, in_len, tgt_len, alpha, nll = ctx.saved_tensors
+        blank, zero_infinity = ctx.cfg
+        B, T, V = logits.shape
+        gl = torch.empty_like(logits)
+        check(_lib.lib().vca_ctc_loss_bwd_f32(B, T, V, targets.shape[1], ptr(logits), targets.data_ptr(),
+                                              in_len.data_ptr(), tgt_len.data_ptr(), blank, 1 if zero_infinity else 0,
+                                              alpha.data_ptr(), ptr(nll), ptr(_c(gnll)), ptr(gl), stream()),
+              'ctc_loss_bwd')
+        return gl, None, None, None, None, None
+
+
+def ctc_nll(logits, targets, in_len, tgt_len, blank=0, zero_infinity=True):
+    """CTC loss per sample, (B,): logits (B, T, V) raw scores, targets (B, Lmax) class ids (padding ignored beyond
+    tgt_len), in_len / tgt_len (B,) valid frames / labels.  blank 0 is the ASR scorer's '_'
+    (ASR_model/GRID/src/data/vid_aud_GRID_test.py:20)."""
+    return CtcNllFn.apply(logits, targets, in_len, tgt_len, int(blank), bool(zero_infinity))
 
 
 # --------------------------------------------------------------------------- #

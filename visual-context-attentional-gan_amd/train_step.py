@@ -79,8 +79,19 @@ class _Heads:
 class GanStep:
     """Callable running one full G+D step; variant 'grid' = train.py, 'lrs' = train_LRS.py."""
 
-    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False):
+    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False, ctc=None):
+        """ctc: None, or dict(front=Audio_front, back=Backend, weight=w): the multi-task configuration (BASELINE
+        configs[4]) adds w * CTC(ASR scorer(g3), text) to gen_loss.  The reference ships that scorer for inference only
+        (ASR_model/GRID/test.py) and has no such training term, so this one is defined here: the scorer is frozen and
+        in eval mode, it reads the generated mel g3 as it is, its frame rate is the video's (mel frames / 4), the loss
+        is torch's ctc_loss 'mean' reduction (per-sample loss / target length, batch mean, blank 0, zero_infinity)."""
         self.m = models
+        self.ctc = ctc
+        if ctc is not None:
+            for k in ('front', 'back'):
+                ctc[k].eval()
+                for p in ctc[k].parameters():
+                    p.requires_grad_(False)
         self.g_opt, self.d_opt = optimizers
         self.variant = variant
         self.gflat = {n: gf for opt in optimizers for n, (_, gf) in opt.flats.items()}
@@ -102,9 +113,10 @@ class GanStep:
         for n in names:
             self.gflat[n].zero_()
 
-    def __call__(self, mel, spec, vid, vid_len, noise=None):
-        """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths."""
-        self.d_phase(mel, spec, vid, vid_len, noise)
+    def __call__(self, mel, spec, vid, vid_len, noise=None, text=None, text_len=None):
+        """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths.
+        text (B, Lmax) class ids and text_len (B,): the transcripts, with ctc= only."""
+        self.d_phase(mel, spec, vid, vid_len, noise, text, text_len)
         self.d_exchange.reduce()
         self.g_phase()
         self.g_exchange.reduce()
@@ -112,9 +124,10 @@ class GanStep:
 
     # The step is three device-only phases separated by the two gradient exchanges, so that a caller can replay
     # each phase as one HIP graph and keep the collectives outside the graphs.
-    def d_phase(self, mel, spec, vid, vid_len, noise=None):
+    def d_phase(self, mel, spec, vid, vid_len, noise=None, text=None, text_len=None):
         """Forward of the generator side, discriminator losses and their backward (train.py:170-210)."""
         m = self.m
+        assert (self.ctc is None) == (text is None), 'transcripts go with the ctc= configuration, and only with it'
         ops.step_begin(mel.device)
         self._zero(G_NAMES)
         ops.rng_advance(mel.device)
@@ -157,7 +170,7 @@ class GanStep:
             out.backward(self._onehot(5, 0, out.device))
         self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
                         tgt=[r.detach() for r in reals], dis_loss=out[0].detach(), sync_loss=out[1].detach(),
-                        grad_p=out[2:5].detach())
+                        grad_p=out[2:5].detach(), text=text, text_len=text_len, vid_len=vid_len)
 
     def _onehot(self, n, i, device):
         """Constant seed gradient selecting slot i of a loss vector (built once, so a captured step holds no fill)."""
@@ -197,18 +210,27 @@ class GanStep:
         for g, t in zip((g1, g2, g3), st['tgt']):
             hd.add(ops.HEAD_L1, g, ((2, 1.0 / 3), (0, 50.0 / 3)), y=t, scale=k / g.numel())
         hd.add(ops.HEAD_L1, gs, ((2, 1.0), (0, 50.0)), y=st['spec'])
-        out = hd.run(4)
+        if self.ctc is not None:             # slot 4 ctc_loss
+            logits = self.ctc['back'](self.ctc['front'](g3))                 # (B, T, 28), one frame per video frame
+            dev = logits.device
+            frames = ops.as_lens(st['vid_len'], dev).clamp(max=logits.shape[1])
+            tl = ops.as_lens(st['text_len'], dev)
+            nll = ops.ctc_nll(logits, st['text'], frames, tl)
+            hd.add(ops.HEAD_SUM, nll / tl.clamp(min=1).to(nll.dtype), ((4, 1.0), (0, float(self.ctc['weight']))))
+        out = hd.run(5 if self.ctc is not None else 4)
         # No gradient buffer needs clearing here: the generator side was cleared at the start of the step and the D
         # phase's backward stops at the detached generator outputs and at phon_d, so it has added nothing to gen /
         # post; the discriminators' parameters take no gradient in this phase.
         with ops.direct_param_grad():
-            torch.autograd.backward([out, phon], [self._onehot(4, 0, out.device), st['phon_d'].grad])
+            torch.autograd.backward([out, phon], [self._onehot(out.numel(), 0, out.device), st['phon_d'].grad])
         for p in d_params:
             p.requires_grad_(True)
         out = out.detach()
         self._st = dict(dis_loss=st['dis_loss'], gen_loss=out[0], sync_loss=st['sync_loss'],
                         g_sync_loss=out[3], recon_loss=out[2], g_loss=out[1],
                         grad_p=st['grad_p'], g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
+        if self.ctc is not None:
+            self._st['ctc_loss'] = out[4]
 
     def finish(self):
         """g_optimizer.step() (train.py:236); returns the step's losses and outputs."""
@@ -230,7 +252,8 @@ class GraphedStep:
     draws it on the GPU from the counter-based generator, so every replay sees new noise; with a tensor the caller
     supplies the noise of every call (passing None on a later call is an error, never a silent reuse)."""
 
-    def __init__(self, step, mel, spec, vid, vid_len, noise='device', warmup=2, segmented=None):
+    def __init__(self, step, mel, spec, vid, vid_len, noise='device', warmup=2, segmented=None, text=None,
+                 text_len=None):
         assert warmup >= 1, 'one uncaptured step must run first: lazy state and the scratch arena settle there'
         self.step = step
         dev = mel.device
@@ -239,6 +262,8 @@ class GraphedStep:
                            vid_len=torch.as_tensor([int(l) for l in vid_len], device=dev))
         if not self.device_noise:
             self.static['noise'] = noise.clone()
+        self.static['text'] = text.to(dev).clone() if text is not None else None
+        self.static['text_len'] = torch.as_tensor(text_len, device=dev).clone() if text is not None else None
         self.segmented = step.d_exchange.active if segmented is None else bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -259,7 +284,7 @@ class GraphedStep:
             pool = torch.cuda.graph_pool_handle()
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
-                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz)
+                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz, s['text'], s['text_len'])
             step.d_exchange.reduce()         # keeps the ranks' collective sequences aligned; the data is not used
             with torch.cuda.graph(self.graphs[1], pool=pool, capture_error_mode=mode):
                 step.g_phase()
@@ -271,10 +296,14 @@ class GraphedStep:
     def _run(self):
         s = self.static
         return self.step(s['mel'], s['spec'], s['vid'], s['vid_len'],
-                         noise='device' if self.device_noise else s['noise'])
+                         noise='device' if self.device_noise else s['noise'], text=s['text'], text_len=s['text_len'])
 
-    def __call__(self, mel, spec, vid, vid_len=None, noise=None):
+    def __call__(self, mel, spec, vid, vid_len=None, noise=None, text=None, text_len=None):
         s = self.static
+        for k, v in (('text', text), ('text_len', text_len)):
+            if v is not None:
+                assert s[k] is not None, 'this step was captured without transcripts'
+                s[k].copy_(torch.as_tensor(v), non_blocking=True)
         if self.device_noise:
             assert noise is None or isinstance(noise, str), 'this step was captured with on-device noise'
         else:
