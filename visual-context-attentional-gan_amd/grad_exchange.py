@@ -8,7 +8,9 @@ import torch.distributed as dist
 class GradExchange:
     """Mean all-reduce of flat gradient buffers.  A side of the step (the discriminators, or v_front + generator +
     postnet) keeps its gradients in one contiguous buffer, so its exchange is a single collective: RCCL averages in
-    the reduction itself (ReduceOp.AVG); backends without it (gloo) sum and scale."""
+    the reduction itself (ReduceOp.AVG); backends without it (gloo) sum and scale.  gloo gets device buffers through
+    a host copy: its collectives on device tensors do not complete on this ROCm stack (both ranks sit in their first
+    broadcast), and gloo is only the fallback for rehearsals of the multi-rank path without one GPU per rank."""
 
     def __init__(self, gflats, group=None, force=False):
         self.group = group
@@ -24,9 +26,14 @@ class GradExchange:
     def reduce(self):
         if not self.active:
             return
-        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
-        works = [dist.all_reduce(g, op=op, group=self.group, async_op=True) for g in self.gflats]
-        for w, g in zip(works, self.gflats):
-            w.wait()
-            if not self.avg:
-                g.mul_(1.0 / self.world)
+        if self.avg:
+            works = [dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=True) for g in self.gflats]
+            for w in works:
+                w.wait()
+            return
+        for g in self.gflats:
+            h = g.cpu() if g.is_cuda else g
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            h.mul_(1.0 / self.world)
+            if g.is_cuda:
+                g.copy_(h)
