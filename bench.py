@@ -160,7 +160,17 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra mixed-precision measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
     ap.add_argument('--precision', default='mixed', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
+    ap.add_argument('--workload', default='grid', choices=['grid', 'lrs', 'lrs_ctc'],
+                    help="grid: BASELINE configs[1] (the headline).  lrs: the train_LRS.py step at configs[3]'s shape "
+                         '(batch 16/GPU, clips padded to T=150, ragged valid lengths).  lrs_ctc: the same with the CTC '
+                         'auxiliary loss of the frozen ASR scorer (configs[4]).  Extra measurements, never the headline.')
     args = ap.parse_args()
+    global T
+    lrs = args.workload != 'grid'
+    if lrs:
+        T = 150
+        if args.batch == B:
+            args.batch = 16
 
     if os.environ.get('VCA_BENCH_HANG_TRACE'):      # debugging aid: dump every thread's stack if the run stalls
         import faulthandler
@@ -200,16 +210,28 @@ def main():
         for k in sorted(models):
             for t in list(models[k].parameters()) + list(models[k].buffers()):
                 dist.broadcast(t.data, 0)
-    opts = train_step.build_optimizers(models)
-    step = train_step.GanStep(models, opts, 'grid')
+    opts = train_step.build_optimizers(models, amsgrad=not lrs)      # train.py:82-83 / train_LRS.py:97-98
+    ctc = None
+    if args.workload == 'lrs_ctc':
+        from vcagan_amd.models import asr
+        ctc = dict(front=asr.Audio_front().to(device), back=asr.Backend().to(device), weight=1.0)
+    step = train_step.GanStep(models, opts, 'lrs' if lrs else 'grid', ctc=ctc)
     data = synth(args.batch, T, H, device, 1234 + rank)
+    text = text_len = None
+    if lrs:
+        g = torch.Generator().manual_seed(7 + rank)
+        data['vid_len'] = [T] + [int(v) for v in torch.randint(T // 3, T + 1, (args.batch - 1,), generator=g)]
+        if ctc is not None:
+            text = torch.randint(1, 28, (args.batch, 40), generator=g).to(device)
+            text_len = torch.randint(10, 41, (args.batch,), generator=g).to(device)
 
     graphed = None
     if not args.no_graph:
         try:
             graphed = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'],
                                              'device',
-                                             segmented=True if os.environ.get('VCA_BENCH_SEGMENTED') == '1' else None)
+                                             segmented=True if os.environ.get('VCA_BENCH_SEGMENTED') == '1' else None,
+                                             text=text, text_len=text_len)
         except Exception as e:       # capture not possible on this stack: fall back to eager launches
             print('graph capture failed, running eagerly: %r' % (e,), file=sys.stderr)
             graphed = None
@@ -223,7 +245,8 @@ def main():
             if graphed is not None:
                 out = graphed(data['mel'], data['spec'], data['vid'])
             else:
-                out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise='device')
+                out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise='device', text=text,
+                           text_len=text_len)
             if trace_loss == 'sync':
                 torch.cuda.synchronize()
             elif trace_loss:
@@ -260,14 +283,18 @@ def main():
         ms = dt / args.steps * 1e3
         frames = args.batch * T * world
         res = {
-            'metric': 'lip-video frames/sec (G+D fwd+bwd step) @ B32xT75x96x96 per GPU',
+            'metric': 'lip-video frames/sec (G+D fwd+bwd step) @ B%dxT%dx96x96 per GPU' % (args.batch, T),
             'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'launch': ('eager' if graphed is None else
                        '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph'),
-            'config': {'workload': 'GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
-                                   'weights' % args.batch, 'global_batch': args.batch * world,
+            'config': {'workload': ('GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
+                                    'weights' % args.batch) if not lrs else
+                                   ('train_LRS.py full GAN step%s, batch %d/GPU, clips padded to 150 frames x 96x96 with '
+                                    'ragged valid lengths (padded frames are counted), mel 80x600, random-init weights'
+                                    % (' + CTC loss of the frozen ASR scorer on the generated mel' if ctc else '',
+                                       args.batch)), 'global_batch': args.batch * world,
                        'parallelism': 'dp%d' % world,
                        'noise': 'decoder noise drawn afresh inside every timed step, on the device (counter-based '
                                 'generator) instead of torch.randn on the CPU + host-to-device copy'},
@@ -276,9 +303,10 @@ def main():
         }
         res['roofline'] = roofline_probe(device, dtype)
         res['dtype_note'] = DTYPE_NOTE.get(dtype, dtype)
-        if world == 1:
+        if world == 1 and not lrs:
             res['north_star'] = north_star_probes(device, models)
-        if world == 1 and graphed is not None and not args.no_alt and args.precision in ('mixed', 'bf16x3'):
+        if (world == 1 and graphed is not None and not args.no_alt and args.precision in ('mixed', 'bf16x3')
+                and not lrs):
             # the same step at the other precision, reported beside `value`, never as `value`
             alt = 'bf16x3' if args.precision == 'mixed' else 'mixed'
             ops.set_precision(alt)
@@ -292,7 +320,7 @@ def main():
             ops.set_precision(args.precision)
             res['alt_precision'] = {'dtype': alt, 'dtype_note': DTYPE_NOTE[alt], 'ms_per_step': round(ms2, 2),
                                     'value': round(frames / (ms2 * 1e-3), 1)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not lrs:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
     if use_dist:
