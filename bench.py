@@ -172,6 +172,13 @@ def main():
         if args.batch == B:
             args.batch = 16
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner of several
+    # lines to stdout when its communicator comes up), so everything this process and its libraries write to file
+    # descriptor 1 goes to stderr, and only the result line is written to the real stdout at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if os.environ.get('VCA_BENCH_HANG_TRACE'):      # debugging aid: dump every thread's stack if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['VCA_BENCH_HANG_TRACE']), exit=True)
@@ -322,7 +329,8 @@ def main():
                                     'value': round(frames / (ms2 * 1e-3), 1)}
         if world == 1 and not args.no_cpu_baseline and not lrs:
             res['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
