@@ -22,6 +22,12 @@ from .models.visual_front import Visual_front
 G_NAMES = ('v_front', 'gen', 'post')
 D_NAMES = ('dis1', 'dis2', 'dis3', 's_dis')
 _LOG_EPS = math.log(1e-5)
+# The three multi-scale discriminators are independent networks, and most of their kernels work on small maps
+# (5x18 ... 20x75) that leave the chip half empty.  With D_STREAMS each one runs on a stream of its own (forward and,
+# because autograd replays an operator's backward on the stream of its forward, backward too), forked from and joined
+# to the step's stream, also inside a captured graph: 80.5 -> 74.0 ms per step at B32 x T75 x 96x96.  VCA_D_STREAMS=0
+# (or train_step.D_STREAMS = False) keeps everything on one stream.
+D_STREAMS = __import__('os').environ.get('VCA_D_STREAMS', '1') != '0'
 
 
 def build_models(temp=1.0, device=None):
@@ -101,6 +107,34 @@ class GanStep:
         if dist.is_available() and dist.is_initialized():
             ops.set_seed(torch.initial_seed(), dist.get_rank(group))   # each replica draws its own dropout masks
 
+    def _each_dis(self, fn, meanwhile=None, n=3):
+        """([fn(0), fn(1), fn(2)], meanwhile()): one call per discriminator, each on its own stream when D_STREAMS is
+        set, and `meanwhile` (work that needs none of their results) on the step's stream before it joins them."""
+        if not D_STREAMS or not torch.cuda.is_available():
+            return [fn(i) for i in range(n)], (meanwhile() if meanwhile is not None else None)
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side', None) is None:
+            self._side = [torch.cuda.Stream() for _ in range(n)]
+        out = []
+        for i in range(n):
+            self._side[i].wait_stream(main)
+            with torch.cuda.stream(self._side[i]):
+                out.append(fn(i))
+        other = meanwhile() if meanwhile is not None else None
+        for i in range(n):
+            main.wait_stream(self._side[i])
+        return out, other
+
+    def _join_dis(self):
+        """The step's stream waits for the discriminators' streams.  After a backward pass this is not implied:
+        autograd only makes the caller's stream wait for streams on which a leaf's gradient was accumulated, and the
+        last kernels of a discriminator's backward (weight gradients added straight into the flat buffer) are
+        followed by none."""
+        if getattr(self, '_side', None) is not None:
+            main = torch.cuda.current_stream()
+            for st in self._side:
+                main.wait_stream(st)
+
     def _zero(self, names):
         """Clear the flat gradients of the named networks; whole sides (contiguous buffers) with one fill."""
         names = tuple(names)
@@ -140,23 +174,24 @@ class GanStep:
         sd = sent.detach()
         dis = (m['dis1'], m['dis2'], m['dis3'])
 
-        real_lo = [d(r, sd, T) for d, r in zip(dis, reals)]
         # The sync loss is the only D-phase term that reaches v_front (train.py:186,210 "accumulate v_front grad").
         # Back-propagation is linear in the incoming gradient, so instead of running v_front's backward twice (once
         # per phase) the D phase stops at the phoneme features and their gradient is added to the G phase's before
         # v_front is traversed once: v_front.grad = J^T (g_D + g_G) = J^T g_D + J^T g_G.
         phon_d = phon.detach().requires_grad_(True)
-        sync = m['s_dis'](phon_d, reals[2])
+        real_lo, sync = self._each_dis(lambda i: dis[i](reals[i], sd, T), lambda: m['s_dis'](phon_d, reals[2]))
         # All loss terms of the phase go through one reduction launch (and one backward launch):
         # slot 0 dis_loss = real + fake + w * sync (train.py:200-205 / train_LRS.py:211-218), 1 sync_loss, 2-4 the R1
         # terms mean_b ||d u_i / d real_i||^2 (train.py:188-194, weight 1/3 each in real_loss).
         hd = _Heads()
         B = mel.size(0)
-        for i, ((u, _), r) in enumerate(zip(real_lo, reals)):
+        def r1(i):
             with ops.input_grads_only():
-                gr, = torch.autograd.grad(u.sum(), r, create_graph=True)
+                return torch.autograd.grad(real_lo[i][0].sum(), reals[i], create_graph=True)[0]
+        for i, gr in enumerate(self._each_dis(r1)[0]):
             hd.add(ops.HEAD_SQSUM, gr, ((2 + i, 1.0), (0, 1.0 / 3)), scale=1.0 / B)
-        fake_lo = [d(g.detach(), sd, T) for d, g in zip(dis, (g1, g2, g3))]
+        fakes = [g.detach() for g in (g1, g2, g3)]
+        fake_lo = self._each_dis(lambda i: dis[i](fakes[i], sd, T))[0]
         for u, c in real_lo:                  # gan_loss(x, True) = mean softplus(-x), generator.py:363-366
             hd.add(ops.HEAD_SOFTPLUS, u, ((0, 1.0 / 3),), sign=-1.0)
             hd.add(ops.HEAD_SOFTPLUS, c, ((0, 1.0 / 3),), sign=-1.0)
@@ -168,6 +203,7 @@ class GanStep:
         self._zero(D_NAMES)
         with ops.direct_param_grad():
             out.backward(self._onehot(5, 0, out.device))
+            self._join_dis()
         self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
                         tgt=[r.detach() for r in reals], dis_loss=out[0].detach(), sync_loss=out[1].detach(),
                         grad_p=out[2:5].detach(), text=text, text_len=text_len, vid_len=vid_len)
@@ -194,9 +230,9 @@ class GanStep:
         d_params = [p for n in D_NAMES for p in m[n].parameters()]
         for p in d_params:
             p.requires_grad_(False)
-        gs = m['post'](g3)
-        gen_lo = [d(g, sd, T) for d, g in zip(dis, (g1, g2, g3))]
-        g_sync = m['s_dis'](phon.detach(), g3, gen=True)
+        gens = (g1, g2, g3)
+        gen_lo, (gs, g_sync) = self._each_dis(lambda i: dis[i](gens[i], sd, T),
+                                              lambda: (m['post'](g3), m['s_dis'](phon.detach(), g3, gen=True)))
         # slot 0 gen_loss, 1 g_loss, 2 recon_loss, 3 g_sync_loss.  GRID (train.py:222-231): g_loss = adv/3 + g_sync,
         # recon = L1(denorm g_i, denorm mel_i)/3 + L1(gs, spec), gen = g_loss + 50 recon; LRS (train_LRS.py:226-237):
         # g_loss = adv/3, recon on the normalised mels, gen = g_loss + 50 recon + g_sync.
@@ -223,6 +259,7 @@ class GanStep:
         # post; the discriminators' parameters take no gradient in this phase.
         with ops.direct_param_grad():
             torch.autograd.backward([out, phon], [self._onehot(out.numel(), 0, out.device), st['phon_d'].grad])
+            self._join_dis()
         for p in d_params:
             p.requires_grad_(True)
         out = out.detach()
