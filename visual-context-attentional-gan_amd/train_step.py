@@ -28,6 +28,9 @@ _LOG_EPS = math.log(1e-5)
 # to the step's stream, also inside a captured graph: 80.5 -> 74.0 ms per step at B32 x T75 x 96x96.  VCA_D_STREAMS=0
 # (or train_step.D_STREAMS = False) keeps everything on one stream.
 D_STREAMS = __import__('os').environ.get('VCA_D_STREAMS', '1') != '0'
+# The full-resolution real mel is a leaf that both dis3 (on its stream) and the sync discriminator (on the step's
+# stream) differentiate: autograd synchronises the two producers itself and warns that it had to.
+__import__('warnings').filterwarnings('ignore', message="The AccumulateGrad node's stream does not match")
 
 
 def build_models(temp=1.0, device=None):
