@@ -111,13 +111,16 @@ class GanStep:
             ops.set_seed(torch.initial_seed(), dist.get_rank(group))   # each replica draws its own dropout masks
 
     def _each_dis(self, fn, meanwhile=None, n=3):
-        """([fn(0), fn(1), fn(2)], meanwhile()): one call per discriminator, each on its own stream when D_STREAMS is
-        set, and `meanwhile` (work that needs none of their results) on the step's stream before it joins them."""
+        """([fn(0), ..., fn(n-1)], meanwhile()): one call per discriminator (and per further independent branch), each
+        on its own stream when D_STREAMS is set, and `meanwhile` (work that needs none of their results) on the step's
+        stream before it joins them."""
         if not D_STREAMS or not torch.cuda.is_available():
             return [fn(i) for i in range(n)], (meanwhile() if meanwhile is not None else None)
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None:
-            self._side = [torch.cuda.Stream() for _ in range(n)]
+            self._side = []
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream())
         out = []
         for i in range(n):
             self._side[i].wait_stream(main)
@@ -234,8 +237,18 @@ class GanStep:
         for p in d_params:
             p.requires_grad_(False)
         gens = (g1, g2, g3)
-        gen_lo, (gs, g_sync) = self._each_dis(lambda i: dis[i](gens[i], sd, T),
-                                              lambda: (m['post'](g3), m['s_dis'](phon.detach(), g3, gen=True)))
+
+        def branch(i):      # 0-2: the discriminators on the generated mels; 3: the ASR scorer's CTC loss (ctc= only)
+            if i < 3:
+                return dis[i](gens[i], sd, T)
+            logits = self.ctc['back'](self.ctc['front'](g3))                 # (B, T, 28), one frame per video frame
+            frames = ops.as_lens(st['vid_len'], logits.device).clamp(max=logits.shape[1])
+            tl = ops.as_lens(st['text_len'], logits.device)
+            return ops.ctc_nll(logits, st['text'], frames, tl) / tl.clamp(min=1).to(logits.dtype)
+
+        lo, (gs, g_sync) = self._each_dis(branch, lambda: (m['post'](g3), m['s_dis'](phon.detach(), g3, gen=True)),
+                                          n=4 if self.ctc is not None else 3)
+        gen_lo = lo[:3]
         # slot 0 gen_loss, 1 g_loss, 2 recon_loss, 3 g_sync_loss.  GRID (train.py:222-231): g_loss = adv/3 + g_sync,
         # recon = L1(denorm g_i, denorm mel_i)/3 + L1(gs, spec), gen = g_loss + 50 recon; LRS (train_LRS.py:226-237):
         # g_loss = adv/3, recon on the normalised mels, gen = g_loss + 50 recon + g_sync.
@@ -249,13 +262,8 @@ class GanStep:
         for g, t in zip((g1, g2, g3), st['tgt']):
             hd.add(ops.HEAD_L1, g, ((2, 1.0 / 3), (0, 50.0 / 3)), y=t, scale=k / g.numel())
         hd.add(ops.HEAD_L1, gs, ((2, 1.0), (0, 50.0)), y=st['spec'])
-        if self.ctc is not None:             # slot 4 ctc_loss
-            logits = self.ctc['back'](self.ctc['front'](g3))                 # (B, T, 28), one frame per video frame
-            dev = logits.device
-            frames = ops.as_lens(st['vid_len'], dev).clamp(max=logits.shape[1])
-            tl = ops.as_lens(st['text_len'], dev)
-            nll = ops.ctc_nll(logits, st['text'], frames, tl)
-            hd.add(ops.HEAD_SUM, nll / tl.clamp(min=1).to(nll.dtype), ((4, 1.0), (0, float(self.ctc['weight']))))
+        if self.ctc is not None:             # slot 4 ctc_loss: batch mean of the per-sample loss / target length
+            hd.add(ops.HEAD_SUM, lo[3], ((4, 1.0), (0, float(self.ctc['weight']))))
         out = hd.run(5 if self.ctc is not None else 4)
         # No gradient buffer needs clearing here: the generator side was cleared at the start of the step and the D
         # phase's backward stops at the detached generator outputs and at phon_d, so it has added nothing to gen /
