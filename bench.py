@@ -302,7 +302,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'launch': ('eager' if graphed is None else
-                       '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph'),
+                       '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph') +
+                      (', the three discriminators on streams of their own' if train_step.D_STREAMS else ''),
             'config': {'workload': ('GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                     'weights' % args.batch) if not lrs else
                                    ('train_LRS.py full GAN step%s, batch %d/GPU, clips padded to 150 frames x 96x96 with '
