@@ -30,7 +30,8 @@ _LOG_EPS = math.log(1e-5)
 D_STREAMS = __import__('os').environ.get('VCA_D_STREAMS', '1') != '0'
 # The full-resolution real mel is a leaf that both dis3 (on its stream) and the sync discriminator (on the step's
 # stream) differentiate: autograd synchronises the two producers itself and warns that it had to.
-__import__('warnings').filterwarnings('ignore', message="The AccumulateGrad node's stream does not match")
+if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
 
 def build_models(temp=1.0, device=None):
