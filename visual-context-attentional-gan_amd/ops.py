@@ -224,6 +224,9 @@ class ConvCfg:
 
 SUBPIXEL_DGRAD = True   # False: stride-2 input gradients over the zero-dilated output gradient (the general form)
 _exact_bwd = [False]   # True while a backward runs under create_graph (its results feed a loss value: R1 penalty)
+_grad_conv = [False]   # True while a forward-type convolution is issued as part of a gradient (the second-order terms
+                       # of the R1 penalty in the discriminators' backward pass): 'mixed' runs it like every other
+                       # gradient, with a single product
 
 
 class use_precision:
@@ -267,7 +270,7 @@ def _conv_fwd_raw(x, w, bias, cfg, stats=None):
     """stats: optional zeroed (2, Cout) tensor receiving per-channel sum / sum of squares of (y - bias)."""
     y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
     d = cfg.desc()
-    ns = _nsplit()
+    ns = _nsplit(_grad_conv[0])
     if ns and cfg.cin > 1 and cfg.kd == 1:
         ws, nws = (None, 0) if stats is not None else _split_ws(cfg, 'fwd', d, x.device)
         check(_lib.lib().vca_conv_fwd_bf16_ws(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
@@ -566,7 +569,9 @@ class ConvDgradFn(torch.autograd.Function):
         cfg = ctx.cfg
         ggx = _c(ggx)
         _exact_bwd[0] = torch.is_grad_enabled()
+        _grad_conv[0] = not torch.is_grad_enabled()
         ggy = ConvFn.apply(ggx, w, None, cfg) if ctx.needs_input_grad[0] else None
+        _grad_conv[0] = False
         gw = None
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(w)
@@ -589,7 +594,9 @@ class ConvWgradFn(torch.autograd.Function):
         ggw = _c(ggw)
         _exact_bwd[0] = torch.is_grad_enabled()
         gx = ConvDgradFn.apply(gy, ggw, cfg) if ctx.needs_input_grad[0] else None
+        _grad_conv[0] = not torch.is_grad_enabled()
         ggy = ConvFn.apply(x, ggw, None, cfg) if ctx.needs_input_grad[1] else None
+        _grad_conv[0] = False
         _exact_bwd[0] = False
         return gx, ggy, None
 
