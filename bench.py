@@ -26,7 +26,8 @@ PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'mixed': 2500.0}
 MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'mixed': 3}
 DTYPE_NOTE = {
     'mixed': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every forward product and '
-             'the R1 double-backward chain, single bf16 products in the input/weight gradients; everything else fp32',
+             'in the gradient chain whose result is the R1 penalty (a loss value), single bf16 products in the '
+             'input/weight gradients incl. the second-order terms of that penalty; everything else fp32',
     'bf16x3': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every product; '
               'everything else fp32',
 }

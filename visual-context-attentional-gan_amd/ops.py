@@ -121,8 +121,8 @@ _precision = ['fp32']
 def set_precision(mode):
     """Arithmetic of the matrix-core convolutions: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, three bf16 MFMAs
     per product, fp32 accumulate: ~fp32 accuracy), 'bf16' (single bf16 product) or 'mixed' (bf16x3 in every forward
-    product, so outputs keep fp32-level parity, and single bf16 products in the input/weight gradients, as bf16
-    mixed-precision training does)."""
+    product and in the gradient chain that yields the R1 penalty, so outputs and loss values keep fp32-level parity,
+    and single bf16 products in the input/weight gradients, as bf16 mixed-precision training does)."""
     assert mode in ('fp32', 'bf16x3', 'bf16', 'mixed')
     _precision[0] = mode
 
