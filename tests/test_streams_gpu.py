@@ -61,7 +61,7 @@ def test_discriminator_streams_change_nothing(prec, graph):
         for k in LOSSES:
             assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
         if i < 2:
-            assert float((a['g3'] - b['g3']).abs().max()) <= (1e-3 if i == 0 else 0.2), i   # two runs of ONE setting: 3e-4
+            assert float((a['g3'] - b['g3']).abs().max()) <= (3e-3 if i == 0 else 0.2), i   # two runs of ONE setting: 3e-4
             assert _rel(b['grad_p'], a['grad_p']) <= (1e-4 if i == 0 else 5e-2), i
     # gradients of the first call (update 0 when eager: 2e-2, the sensitivity of this network's gradients to last-bit
     # changes; update 1 under replay: finite) and the parameters after the updates (Adam steps are lr-sized)
