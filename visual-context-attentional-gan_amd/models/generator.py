@@ -254,7 +254,6 @@ class Decoder(nn.Module):
         the string 'device' draws it on the GPU instead (ops.randn: no host draw and no host-to-device copy, fresh
         values on every replay of a captured step; not torch's random stream)."""
         B, T = x.size(0), x.size(1)
-        ctx = s.transpose(1, 2).contiguous()                             # (B, T, 512)
         len = ops.as_lens(len, x.device)
         if isinstance(noise, str):
             assert noise == 'device', noise
@@ -272,6 +271,7 @@ class Decoder(nn.Module):
         for block in self.g1:
             h = block(h)
         m1, h = self._mel(self.to_mel1, h, skip=True)
+        ctx = ops.ensure_ready(s).transpose(1, 2).contiguous()           # (B, T, 512); first use of s
         h = _conv(ops.concat2(h, self.att1(ctx, h, len), B, h.shape[1], h.shape[2]), self.attconv1)
         for block in self.g2:
             h = block(h)

@@ -1,4 +1,5 @@
 """Visual front-end (mirror of the reference's src/models/visual_front.py:4-37)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -18,6 +19,7 @@ class Visual_front(nn.Module):
         self.dropout = nn.Dropout(0.3)
         self.sentence_encoder = nn.GRU(512, 512, 2, bidirectional=True, dropout=0.3)
         self.fc = nn.Linear(1024, 512)
+        self.defer_sentence = False     # see forward(); set by a caller that waits for the sentence features itself
 
     def front(self, x):
         """The 3-D front-end (visual_front.py:11-14,25-27): x (B, T, H, W, 1) channels-last clip -> (B*T, H/4, W/4, 64)
@@ -34,6 +36,20 @@ class Visual_front(nn.Module):
         f = self.front(x.reshape(B, T, H, W, 1))
         f = self.resnet(f)                                                           # (B*T, 512)
         f = ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
+        if getattr(self, 'defer_sentence', False) and f.is_cuda:
+            # The recurrence is 2 x T launches of a few microseconds each, and the decoder does not read the sentence
+            # features before its first attention module: on a side stream it runs beside the decoder's first blocks
+            # (and its backward pass beside the second half of the decoder's).  The caller has asked for this and
+            # calls ops.ensure_ready(sent) before it reads the tensor.
+            cur, side = torch.cuda.current_stream(), ops.side_stream('sentence')
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                sent = self._sentence(f)
+            sent._vca_stream = side
+            return f, sent
+        return f, self._sentence(f)
+
+    def _sentence(self, f):
         sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)
         sent = ops.linear(sent, self.fc.weight, self.fc.bias)                        # (B, T, 512)
-        return f, sent.transpose(1, 2).contiguous()
+        return sent.transpose(1, 2).contiguous()

@@ -363,6 +363,34 @@ def _flush_wgrads():
 
 _inputs_only = [False]  # set by input_grads_only()
 
+# A module may compute one of its outputs on a side stream so that a latency-bound chain (the sentence encoder's GRU)
+# runs beside its caller's next kernels.  Such an output carries the stream it is produced on until a consumer calls
+# ensure_ready(), which makes the current stream wait for it.  Only callers that do so ask for deferred outputs.
+_side_streams = {}
+
+
+def side_stream(key):
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream()
+    return s
+
+
+def ensure_ready(t):
+    """The current stream waits for the side stream tensor t was produced on, if any."""
+    s = getattr(t, '_vca_stream', None)
+    if s is not None:
+        torch.cuda.current_stream().wait_stream(s)
+    return t
+
+
+def join_side_streams():
+    """The current stream waits for every side stream (after a backward pass, whose last kernels on a side stream,
+    gradients added straight into the flat buffers, nothing else waits for)."""
+    cur = torch.cuda.current_stream()
+    for s in _side_streams.values():
+        cur.wait_stream(s)
+
 
 class input_grads_only:
     """While active, convolution / linear backward passes skip the weight and bias gradients.  For

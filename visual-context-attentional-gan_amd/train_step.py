@@ -149,6 +149,7 @@ class GanStep:
             main = torch.cuda.current_stream()
             for st in self._side:
                 main.wait_stream(st)
+        ops.join_side_streams()
 
     def _zero(self, names):
         """Clear the flat gradients of the named networks; whole sides (contiguous buffers) with one fill."""
@@ -182,8 +183,16 @@ class GanStep:
         ops.rng_advance(mel.device)
         mel1 = ops.mel_down(mel, 4)          # F.interpolate(mel, scale_factor=0.25, mode='bilinear'), train.py:170
         mel2 = ops.mel_down(mel, 2)
-        phon, sent = m['v_front'](vid)
+        # The sentence encoder (a bi-GRU: 2 x T launches of a few microseconds) on a side stream beside the decoder's
+        # first blocks, which do not read its output: requested for this call only, because the output then has to be
+        # waited for (ops.ensure_ready) by whoever reads it; the decoder does so before its first attention module.
+        m['v_front'].defer_sentence = D_STREAMS
+        try:
+            phon, sent = m['v_front'](vid)
+        finally:
+            m['v_front'].defer_sentence = False
         g1, g2, g3 = m['gen'](sent, phon, vid_len, noise=noise)
+        ops.ensure_ready(sent)
         reals = [t.detach().clone().requires_grad_(True) for t in (mel1, mel2, mel)]
         T = phon.size(1)
         sd = sent.detach()
