@@ -154,8 +154,8 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=B)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra mixed-precision measurement')
@@ -304,7 +304,7 @@ def main():
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'launch': ('eager' if graphed is None else
                        '3 hip-graphs + 2 all-reduces' if graphed.segmented else 'hip-graph') +
-                      (', the three discriminators on streams of their own' if train_step.D_STREAMS else ''),
+                      (', the discriminators and the sentence encoder on side streams' if train_step.D_STREAMS else ''),
             'config': {'workload': ('GRID full GAN step, batch %d/GPU x 75 frames x 96x96, mel 80x300, random-init '
                                     'weights' % args.batch) if not lrs else
                                    ('train_LRS.py full GAN step%s, batch %d/GPU, clips padded to 150 frames x 96x96 with '
