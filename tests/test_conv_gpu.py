@@ -21,6 +21,9 @@ CASES = [
     (2, 10, 7, 16, 32, 5, 1, 2, 1),        # conv over a nearest x2 upsample
     (2, 20, 13, 1, 32, 5, 1, 2, 0),        # single-channel input (discriminator stem)
     (2, 20, 14, 1, 128, 3, 2, 1, 0),       # sync discriminator stem
+    (8, 80, 37, 1, 16, 5, 1, 2, 0),        # single-channel input: more output rows than partial-sum slabs
+    (3, 21, 15, 1, 40, 3, 2, 1, 0),        # single-channel input, stride 2 on odd sizes, Cout not a multiple of 32
+    (2, 9, 10, 1, 8, 3, 1, 0, 0),          # single-channel input, no padding
     (2, 8, 9, 32, 1, 1, 1, 0, 0),          # to_mel 1x1 to one channel
     (1, 6, 5, 80, 321, 1, 1, 0, 0),        # odd Cout
     (1, 7, 6, 321, 16, 1, 1, 0, 0),        # odd Cin

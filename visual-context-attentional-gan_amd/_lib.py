@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
-           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip')
+           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip', 'wgrad_cin1.hip')
 
 
 def build(force=False, verbose=False):
@@ -65,6 +65,8 @@ _SIGS = {
     'vca_conv_fwd_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10, _I),
     'vca_conv_fwd_bf16_ws': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10 + [_LL, _P], _I),
     'vca_conv_fwd_bf16_ws_floats': ([ctypes.POINTER(ConvDesc)], _LL),
+    'vca_conv_wgrad_cin1_ws_floats': ([ctypes.POINTER(ConvDesc)], _LL),
+    'vca_conv_wgrad_cin1_f32': ([ctypes.POINTER(ConvDesc), _P, _P, _P, _LL, _P, _P], _I),
     'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 8, _I),
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),

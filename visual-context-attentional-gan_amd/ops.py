@@ -467,8 +467,14 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None, bias_sink=None):
         _bias_done[0] = bias_sink is not None
     else:
         _bias_done[0] = False
-        check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
-              'conv_wgrad')
+        nws = _lib.lib().vca_conv_wgrad_cin1_ws_floats(cfg.desc()) if cin == 1 else 0
+        if nws:
+            ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
+            check(_lib.lib().vca_conv_wgrad_cin1_f32(cfg.desc(), ptr(x), ptr(gy), ptr(ws), nws, ptr(dwp), stream()),
+                  'conv_wgrad_cin1')
+        else:
+            check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
+                  'conv_wgrad')
     if deferred:
         return None
     gw = sink if sink is not None else torch.empty(cfg.pshape, device=x.device, dtype=torch.float32)
