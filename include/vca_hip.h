@@ -126,11 +126,12 @@ int vca_conv_wgrad_bf16(const vca_conv_desc* d, int nsplit, const float* x, cons
 /* Weight gradient of a 2-D convolution with ONE input channel and a 5x5 or 3x3 filter (first layer of the mel
  * discriminators, generator.py:291, and of the sync discriminator, generator.py:346): one streaming pass over gy on
  * the vector units, input rows in LDS, partial sums per workgroup in slabs of ws (fixed summation order), folded and
- * ADDED to dwpack[tap][1][Cout4] like vca_conv_wgrad_f32 does.  vca_conv_wgrad_cin1_ws_floats returns the workspace
- * size in floats, 0 for a descriptor this kernel does not cover (the caller then uses vca_conv_wgrad_f32). */
+ * ADDED to dwpack[tap][1][Cout4] like vca_conv_wgrad_f32 does.  bias_grad (may be NULL): [Cout] vector to which the
+ * column sums of gy are ADDED, from the same pass.  vca_conv_wgrad_cin1_ws_floats returns the workspace size in
+ * floats, 0 for a descriptor this kernel does not cover (the caller then uses vca_conv_wgrad_f32). */
 long long vca_conv_wgrad_cin1_ws_floats(const vca_conv_desc* d);
 int vca_conv_wgrad_cin1_f32(const vca_conv_desc* d, const float* x, const float* gy, float* ws, long long ws_floats,
-                            float* dwpack, void* stream);
+                            float* dwpack, float* bias_grad, void* stream);
 /* mode 2 (taps = 9): the input gradient of a 3x3 / stride 2 / padding 1 convolution in sub-pixel form: 4 taps
  * (dy, dx) over the output gradient, N = 4*Cin columns (ry, rx, ci), K = Cout; for a descriptor with KH = KW = 2,
  * stride 1, padding 0, OH x OW = the output gradient's size and d2s_h x d2s_w = the input's. */

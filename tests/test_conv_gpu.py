@@ -170,7 +170,8 @@ def test_stem_kernel(shape, prec, tol):
 @gpu
 @pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('mixed', 1.5e-2)])
 @pytest.mark.parametrize('case', [(3, 9, 11, 32, 48, 5, 2), (4, 12, 12, 64, 100, 3, 1), (2, 6, 7, 96, 33, 1, 0),
-                                  (2, 20, 13, 64, 64, 5, 2)])
+                                  (2, 20, 13, 64, 64, 5, 2),
+                                  (3, 20, 31, 1, 32, 5, 2), (2, 9, 14, 1, 40, 3, 1)])    # single-channel input
 def test_conv2d_gradients_into_sinks(case, prec, tol):
     """Parameters that own a preallocated gradient (the flat buffers of a training step) receive the weight gradient
     through the per-parameter workspace and the bias gradient from the weight-gradient kernel itself (column sums of

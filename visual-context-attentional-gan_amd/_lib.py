@@ -66,7 +66,7 @@ _SIGS = {
     'vca_conv_fwd_bf16_ws': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 10 + [_LL, _P], _I),
     'vca_conv_fwd_bf16_ws_floats': ([ctypes.POINTER(ConvDesc)], _LL),
     'vca_conv_wgrad_cin1_ws_floats': ([ctypes.POINTER(ConvDesc)], _LL),
-    'vca_conv_wgrad_cin1_f32': ([ctypes.POINTER(ConvDesc), _P, _P, _P, _LL, _P, _P], _I),
+    'vca_conv_wgrad_cin1_f32': ([ctypes.POINTER(ConvDesc), _P, _P, _P, _LL, _P, _P, _P], _I),
     'vca_conv_wgrad_bf16': ([ctypes.POINTER(ConvDesc), _I] + [_P] * 8, _I),
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),

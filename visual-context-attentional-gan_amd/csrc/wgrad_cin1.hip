@@ -5,7 +5,8 @@
 // multiply-adds per element against a few input rows held in LDS.  A workgroup walks over output rows; a thread owns
 // one output channel and every filter tap (registers) for one of eight pixel lanes.  Workgroups store their partial
 // sums in slabs of a caller-provided workspace (plain stores, fixed summation order); a second kernel folds the slabs
-// into the [tap][1][Cout4] accumulation buffer the other weight-gradient kernels use.
+// into the [tap][1][Cout4] accumulation buffer the other weight-gradient kernels use.  The column sums of gy (the
+// gradient of the convolution's bias) ride along as one more row of every slab.
 #include "common.h"
 
 namespace {
@@ -19,15 +20,16 @@ struct C1Args {
   int N, Hin, Win, OH, OW, Cout, Cout4, stride, pad_h, pad_w, nwg;
   const float* x;
   const float* gy;
-  float* slabs;   // [cgroups][nwg][KH*KW][CG]
+  float* slabs;   // [cgroups][nwg][KH*KW + 1][CG]; the last row: column sums of gy
   float* dw;      // [KH*KW][Cout4]
+  float* bias;    // [Cout] or null
 };
 
 template <int KH, int KW>
 __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
   constexpr int TAPS = KH * KW;
   __shared__ float xs[KH][MAXW + 8];
-  __shared__ float red[PL][TAPS][CG];
+  __shared__ float red[PL][TAPS + 1][CG];
   const int tid = threadIdx.x, co = tid & (CG - 1), pl = tid / CG;
   const int cg0 = blockIdx.y * CG;
   const bool cok = cg0 + co < a.Cout;
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
   float acc[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
+  float accb = 0.f;
   const int rows = a.N * a.OH;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / a.OH, oy = r - n * a.OH;
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
     for (int ox = pl; ox < a.OW; ox += PL) {
       const float v = cok ? g[(size_t)ox * a.Cout] : 0.f;
       const int c0 = ox * a.stride;
+      accb += v;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
@@ -60,9 +64,10 @@ __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
   }
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) red[pl][t][co] = acc[t];
+  red[pl][TAPS][co] = accb;
   __syncthreads();
-  float* slab = a.slabs + ((size_t)blockIdx.y * a.nwg + blockIdx.x) * TAPS * CG;
-  for (int i = tid; i < TAPS * CG; i += CG * PL) {
+  float* slab = a.slabs + ((size_t)blockIdx.y * a.nwg + blockIdx.x) * (TAPS + 1) * CG;
+  for (int i = tid; i < (TAPS + 1) * CG; i += CG * PL) {
     const int t = i / CG, c = i - t * CG;
     float s = 0.f;
 #pragma unroll
@@ -71,12 +76,12 @@ __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
   }
 }
 
-// dw[tap][cg*CG + c] += sum over the nwg slabs of channel group cg.  A workgroup owns 64 consecutive (tap, c)
-// entries of one channel group; 16 thread rows stride over the slabs.
+// dw[tap][cg*CG + c] += sum over the nwg slabs of channel group cg (row `taps` of a slab goes to bias[]).  A
+// workgroup owns 64 consecutive (tap, c) entries of one channel group; 16 thread rows stride over the slabs.
 __global__ __launch_bounds__(1024) void wgrad_cin1_fold_kernel(int taps, C1Args a) {
   __shared__ float red[16][64];
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int cg = blockIdx.y, e = blockIdx.x * 64 + c, n = taps * CG;
+  const int cg = blockIdx.y, e = blockIdx.x * 64 + c, n = (taps + 1) * CG;
   float s = 0.f;
   if (e < n) {
     const float* p = a.slabs + (size_t)cg * a.nwg * n + e;
@@ -88,7 +93,10 @@ __global__ __launch_bounds__(1024) void wgrad_cin1_fold_kernel(int taps, C1Args 
 #pragma unroll
     for (int i = 1; i < 16; ++i) s += red[i][c];
     const int t = e / CG, ch = cg * CG + (e - t * CG);
-    if (ch < a.Cout) atomicAdd(a.dw + (size_t)t * a.Cout4 + ch, s);
+    if (ch < a.Cout) {
+      if (t < taps) atomicAdd(a.dw + (size_t)t * a.Cout4 + ch, s);
+      else if (a.bias) atomicAdd(a.bias + ch, s);
+    }
   }
 }
 
@@ -113,11 +121,11 @@ int workgroups(const vca_conv_desc* d) {
 extern "C" long long vca_conv_wgrad_cin1_ws_floats(const vca_conv_desc* d) {
   if (!supported(d)) return 0;
   const long long cgroups = (d->Cout + CG - 1) / CG;
-  return cgroups * workgroups(d) * d->KH * d->KW * CG;
+  return cgroups * workgroups(d) * (d->KH * d->KW + 1) * CG;
 }
 
 extern "C" int vca_conv_wgrad_cin1_f32(const vca_conv_desc* d, const float* x, const float* gy, float* ws,
-                                       long long ws_floats, float* dwpack, void* stream) {
+                                       long long ws_floats, float* dwpack, float* bias_grad, void* stream) {
   VCA_CHECK_ARG(supported(d) && x && gy && ws && dwpack);
   VCA_CHECK_ARG(ws_floats >= vca_conv_wgrad_cin1_ws_floats(d));
   C1Args a;
@@ -125,7 +133,7 @@ extern "C" int vca_conv_wgrad_cin1_f32(const vca_conv_desc* d, const float* x, c
   a.Cout4 = (d->Cout + 3) & ~3;
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.nwg = workgroups(d);
-  a.x = x; a.gy = gy; a.slabs = ws; a.dw = dwpack;
+  a.x = x; a.gy = gy; a.slabs = ws; a.dw = dwpack; a.bias = bias_grad;
   const int cgroups = (d->Cout + CG - 1) / CG;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.nwg, cgroups);
@@ -134,6 +142,6 @@ extern "C" int vca_conv_wgrad_cin1_f32(const vca_conv_desc* d, const float* x, c
     hipLaunchKernelGGL((wgrad_cin1_partial_kernel<5, 5>), grid, dim3(CG * PL), 0, s, a);
   else
     hipLaunchKernelGGL((wgrad_cin1_partial_kernel<3, 3>), grid, dim3(CG * PL), 0, s, a);
-  hipLaunchKernelGGL(wgrad_cin1_fold_kernel, dim3((taps * CG + 63) / 64, cgroups), dim3(1024), 0, s, taps, a);
+  hipLaunchKernelGGL(wgrad_cin1_fold_kernel, dim3(((taps + 1) * CG + 63) / 64, cgroups), dim3(1024), 0, s, taps, a);
   return vca_launch_status();
 }

@@ -470,8 +470,9 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None, bias_sink=None):
         nws = _lib.lib().vca_conv_wgrad_cin1_ws_floats(cfg.desc()) if cin == 1 else 0
         if nws:
             ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
-            check(_lib.lib().vca_conv_wgrad_cin1_f32(cfg.desc(), ptr(x), ptr(gy), ptr(ws), nws, ptr(dwp), stream()),
-                  'conv_wgrad_cin1')
+            check(_lib.lib().vca_conv_wgrad_cin1_f32(cfg.desc(), ptr(x), ptr(gy), ptr(ws), nws, ptr(dwp),
+                                                     ptr(bias_sink), stream()), 'conv_wgrad_cin1')
+            _bias_done[0] = bias_sink is not None
         else:
             check(_lib.lib().vca_conv_wgrad_f32(cfg.desc(), ptr(x), ptr(gy), None, None, None, ptr(dwp), stream()),
                   'conv_wgrad')
