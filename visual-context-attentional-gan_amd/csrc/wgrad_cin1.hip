@@ -2,8 +2,9 @@
 // generator.py:291: Conv2d(1, dim_in, 5, 1, 2); of the sync discriminator, generator.py:346: Conv2d(1, 128, 3, 2, 1)):
 //   dw[tap][co] = sum over output pixels p of gy[p][co] * x[p (+) tap].
 // There is no channel reduction to feed the matrix cores with: the work is one pass over gy (HBM-bound) with KH*KW
-// multiply-adds per element against a few input rows held in LDS.  A workgroup walks over output rows; a thread owns
-// one output channel and every filter tap (registers) for one of eight pixel lanes.  Workgroups store their partial
+// multiply-adds per element against a few input rows held in LDS.  A workgroup walks over groups of up to four
+// consecutive output rows; a thread owns one output channel and every filter tap (registers) for one of eight pixel
+// lanes and requests eight output-gradient values ahead of their use.  Workgroups store their partial
 // sums in slabs of a caller-provided workspace (plain stores, fixed summation order); a second kernel folds the slabs
 // into the [tap][1][Cout4] accumulation buffer the other weight-gradient kernels use.  The column sums of gy (the
 // gradient of the convolution's bias) ride along as one more row of every slab.
@@ -13,11 +14,14 @@ namespace {
 
 constexpr int CG = 32;        // output channels per workgroup (one per lane of a half-wave)
 constexpr int PL = 8;         // pixel lanes per workgroup
-constexpr int MAXW = 1024;    // widest input row staged in LDS
-constexpr int MAXWG = 512;    // workgroups (slabs) per channel group
+constexpr int MAXW = 640;     // widest padded input row staged in LDS
+constexpr int MAXWG = 1024;   // workgroups (slabs) per channel group
+constexpr int RC = 4;         // consecutive output rows per work unit (their input rows are staged together)
+constexpr int PF = 8;         // output-gradient values a thread requests before it uses the first
 
 struct C1Args {
   int N, Hin, Win, OH, OW, Cout, Cout4, stride, pad_h, pad_w, nwg;
+  int rc, chunks;  // output rows per work unit, work units per image
   const float* x;
   const float* gy;
   float* slabs;   // [cgroups][nwg][KH*KW + 1][CG]; the last row: column sums of gy
@@ -28,8 +32,11 @@ struct C1Args {
 template <int KH, int KW>
 __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
   constexpr int TAPS = KH * KW;
-  __shared__ float xs[KH][MAXW + 8];
-  __shared__ float red[PL][TAPS + 1][CG];
+  constexpr int XROWS = (RC - 1) * 2 + KH;                       // stride <= 2
+  constexpr int XS = XROWS * (MAXW + 8), RED = PL * (TAPS + 1) * CG;
+  __shared__ float smem[XS > RED ? XS : RED];
+  float(*xs)[MAXW + 8] = reinterpret_cast<float(*)[MAXW + 8]>(smem);
+  float(*red)[TAPS + 1][CG] = reinterpret_cast<float(*)[TAPS + 1][CG]>(smem);   // after the last unit
   const int tid = threadIdx.x, co = tid & (CG - 1), pl = tid / CG;
   const int cg0 = blockIdx.y * CG;
   const bool cok = cg0 + co < a.Cout;
@@ -38,30 +45,43 @@ __global__ __launch_bounds__(CG* PL) void wgrad_cin1_partial_kernel(C1Args a) {
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
   float accb = 0.f;
-  const int rows = a.N * a.OH;
-  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-    const int n = r / a.OH, oy = r - n * a.OH;
+  const int units = a.N * a.chunks;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n = u / a.chunks, oy0 = (u - n * a.chunks) * a.rc;
+    const int nr = min(a.rc, a.OH - oy0);
+    const int xrows = (nr - 1) * a.stride + KH;
     __syncthreads();
-    for (int i = tid; i < KH * LW; i += CG * PL) {
-      const int kh = i / LW, c = i - kh * LW;
-      const int iy = oy * a.stride + kh - a.pad_h, ix = c - a.pad_w;
+    for (int i = tid; i < xrows * LW; i += CG * PL) {
+      const int xr = i / LW, c = i - xr * LW;
+      const int iy = oy0 * a.stride + xr - a.pad_h, ix = c - a.pad_w;
       float v = 0.f;
       if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = a.x[((size_t)n * a.Hin + iy) * a.Win + ix];
-      xs[kh][c] = v;
+      xs[xr][c] = v;
     }
     __syncthreads();
-    const float* g = a.gy + (size_t)r * a.OW * a.Cout + cg0 + co;
-#pragma unroll 4
-    for (int ox = pl; ox < a.OW; ox += PL) {
-      const float v = cok ? g[(size_t)ox * a.Cout] : 0.f;
-      const int c0 = ox * a.stride;
-      accb += v;
+    for (int rr = 0; rr < nr; ++rr) {
+      const float* g = a.gy + ((size_t)(n * a.OH + oy0 + rr) * a.OW) * a.Cout + cg0 + co;
+      const int xr0 = rr * a.stride;
+      for (int ox0 = pl; ox0 < a.OW; ox0 += PL * PF) {
+        float v[PF];
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh)
+        for (int j = 0; j < PF; ++j) {
+          const int ox = ox0 + j * PL;
+          v[j] = (cok && ox < a.OW) ? g[(size_t)ox * a.Cout] : 0.f;
+        }
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) acc[kh * KW + kw] += v * xs[kh][c0 + kw];
+        for (int j = 0; j < PF; ++j) {
+          const int c0 = min(ox0 + j * PL, a.OW - 1) * a.stride;   // past the row: v = 0, any staged column will do
+          accb += v[j];
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) acc[kh * KW + kw] += v[j] * xs[xr0 + kh][c0 + kw];
+        }
+      }
     }
   }
+  __syncthreads();
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) red[pl][t][co] = acc[t];
   red[pl][TAPS][co] = accb;
@@ -102,7 +122,7 @@ __global__ __launch_bounds__(1024) void wgrad_cin1_fold_kernel(int taps, C1Args 
 
 bool supported(const vca_conv_desc* d) {
   if (!d || d->Cin != 1 || d->KD != 1 || d->D != 1 || d->OD != 1 || d->pad_d != 0 || d->dil != 1 || d->ups != 0 ||
-      d->act != 0 || d->stride < 1)
+      d->act != 0 || d->stride < 1 || d->stride > 2)
     return false;
   if (!((d->KH == 5 && d->KW == 5) || (d->KH == 3 && d->KW == 3))) return false;
   if (d->Win + 2 * d->pad_w > MAXW || d->N <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return false;
@@ -111,9 +131,20 @@ bool supported(const vca_conv_desc* d) {
   return (long long)d->N * d->OH * d->OW * d->Cout < (1ll << 31);
 }
 
-int workgroups(const vca_conv_desc* d) {
+// Output rows per work unit: as many as keep every CU supplied with a few workgroups.
+int rows_per_unit(const vca_conv_desc* d) {
   const long long rows = (long long)d->N * d->OH;
-  return (int)(rows < MAXWG ? rows : MAXWG);
+  return rows >= 2048 ? RC : rows >= 1024 ? 2 : 1;
+}
+
+int units_per_image(const vca_conv_desc* d) {
+  const int rc = rows_per_unit(d);
+  return (d->OH + rc - 1) / rc;
+}
+
+int workgroups(const vca_conv_desc* d) {
+  const long long units = (long long)d->N * units_per_image(d);
+  return (int)(units < MAXWG ? units : MAXWG);
 }
 
 }  // namespace
@@ -133,6 +164,8 @@ extern "C" int vca_conv_wgrad_cin1_f32(const vca_conv_desc* d, const float* x, c
   a.Cout4 = (d->Cout + 3) & ~3;
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.nwg = workgroups(d);
+  a.rc = rows_per_unit(d);
+  a.chunks = units_per_image(d);
   a.x = x; a.gy = gy; a.slabs = ws; a.dw = dwpack; a.bias = bias_grad;
   const int cgroups = (d->Cout + CG - 1) / CG;
   hipStream_t s = (hipStream_t)stream;
