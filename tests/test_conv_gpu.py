@@ -24,8 +24,9 @@ CASES = [
     (8, 80, 37, 1, 16, 5, 1, 2, 0),        # single-channel input: more output rows than partial-sum slabs
     (3, 21, 15, 1, 40, 3, 2, 1, 0),        # single-channel input, stride 2 on odd sizes, Cout not a multiple of 32
     (2, 9, 10, 1, 8, 3, 1, 0, 0),          # single-channel input, no padding
-    (16, 130, 21, 1, 32, 5, 1, 2, 0),      # single-channel input: groups of 4 output rows with a tail of 2
-    (8, 131, 20, 1, 24, 3, 2, 1, 0),       # single-channel input: groups of 2 output rows, stride 2, odd height
+    (16, 130, 21, 1, 32, 5, 1, 2, 0),      # single-channel input: groups of 2 output rows
+    (40, 70, 9, 1, 32, 5, 1, 2, 0),        # single-channel input: groups of 4 output rows with a tail of 2
+    (24, 131, 20, 1, 24, 3, 2, 1, 0),      # single-channel input: groups of 2 output rows, stride 2, odd height
     (2, 8, 9, 32, 1, 1, 1, 0, 0),          # to_mel 1x1 to one channel
     (1, 6, 5, 80, 321, 1, 1, 0, 0),        # odd Cout
     (1, 7, 6, 321, 16, 1, 1, 0, 0),        # odd Cin

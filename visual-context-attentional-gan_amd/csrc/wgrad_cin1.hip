@@ -15,7 +15,7 @@ namespace {
 constexpr int CG = 32;        // output channels per workgroup (one per lane of a half-wave)
 constexpr int PL = 8;         // pixel lanes per workgroup
 constexpr int MAXW = 640;     // widest padded input row staged in LDS
-constexpr int MAXWG = 1024;   // workgroups (slabs) per channel group
+constexpr int MAXWG = 1280;   // workgroups (slabs) per channel group: five per CU, all resident at once
 constexpr int RC = 4;         // consecutive output rows per work unit (their input rows are staged together)
 constexpr int PF = 8;         // output-gradient values a thread requests before it uses the first
 
@@ -105,7 +105,16 @@ __global__ __launch_bounds__(1024) void wgrad_cin1_fold_kernel(int taps, C1Args 
   float s = 0.f;
   if (e < n) {
     const float* p = a.slabs + (size_t)cg * a.nwg * n + e;
-    for (int w = r; w < a.nwg; w += 16) s += p[(size_t)w * n];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = r;
+    for (; w + 48 < a.nwg; w += 64) {          // four independent chains of loads
+      s += p[(size_t)w * n];
+      s1 += p[(size_t)(w + 16) * n];
+      s2 += p[(size_t)(w + 32) * n];
+      s3 += p[(size_t)(w + 48) * n];
+    }
+    for (; w < a.nwg; w += 16) s += p[(size_t)w * n];
+    s += s1 + s2 + s3;
   }
   red[r][c] = s;
   __syncthreads();
@@ -134,7 +143,9 @@ bool supported(const vca_conv_desc* d) {
 // Output rows per work unit: as many as keep every CU supplied with a few workgroups.
 int rows_per_unit(const vca_conv_desc* d) {
   const long long rows = (long long)d->N * d->OH;
-  return rows >= 2048 ? RC : rows >= 1024 ? 2 : 1;
+  int rc = 1;
+  while (rc < RC && rows > (long long)MAXWG * rc) rc *= 2;     // the fewest rows per unit that fit one unit per workgroup
+  return rc;
 }
 
 int units_per_image(const vca_conv_desc* d) {
