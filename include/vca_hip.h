@@ -280,7 +280,8 @@ int vca_gru_cell_bwd2_f32(int B, int H, int dout_stride, const float* dout0, con
 /* One forward time step of both directions of a bidirectional GRU layer (nn.GRU, visual_front.py:20,33-34) in one
  * launch: gh = h_prev . W_hh^T + b_hh on the matrix cores (W packed by vca_pack_weight_bf16 mode 0, [3H][H]) with the
  * gate arithmetic of vca_gru_cell_fwd2_f32 in the epilogue.  hp0/hp1 NULL = zero initial state.  gi: [B][3H] input
- * gates of this step; writes h_new [B][H], out (row stride out_stride) and save [B][4H] = (r, z, n, gh_n). */
+ * gates of this step; writes h_new [B][H], out (row stride out_stride) and save [B][4H] = (r, z, n, gh_n).
+ * H must be a multiple of 16 (the reduction is read in 16-wide slices); other sizes return -22. */
 int vca_gru_fwd_step_bf16(int nsplit, int B, int H, const float* hp0, const float* hp1, const void* w0, const void* w1,
                           const float* bhh0, const float* bhh1, const float* gi0, const float* gi1, float* hn0,
                           float* hn1, float* out0, float* out1, int out_stride, float* save0, float* save1,

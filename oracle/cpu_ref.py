@@ -363,8 +363,12 @@ def build_optimizers(models, lr=1e-4, weight_decay=1e-5, amsgrad=True):
     return g, d
 
 
-def gan_step(models, optimizers, batch, variant='grid', noise=None, ctc=None):
+def gan_step(models, optimizers, batch, variant='grid', noise=None, ctc=None, on_d_backward=None):
     """One full G+D step.  batch = dict(mel (B,1,80,4T), spec (B,1,321,4T), vid (B,1,T,H,W), vid_len).
+
+    on_d_backward: None or a callable(models, phon) run right after dis_loss.backward() and before
+    d_optimizer.step() (train.py:210-211): the only moment at which the discriminators hold the gradient their
+    optimizer consumes and v_front holds the sync-loss contribution alone; phon.grad is d dis_loss / d phon.
 
     ctc: None or dict(front, back, weight): the multi-task extension (no counterpart in the reference's training
     scripts; its ASR scorer, ASR_model/GRID/src/models, is used frozen and in eval mode): gen_loss gains
@@ -401,7 +405,12 @@ def gan_step(models, optimizers, batch, variant='grid', noise=None, ctc=None):
     sync_w = 1.0 if variant == 'grid' else 0.5
     dis_loss = real_loss + fake_loss + sync_w * sync_loss
     d_opt.zero_grad()
+    if on_d_backward is not None:
+        phon.retain_grad()
     dis_loss.backward(retain_graph=True)
+    if on_d_backward is not None:
+        on_d_backward(m, phon)
+        phon.grad = None
     d_opt.step()
 
     # ---- G phase ----

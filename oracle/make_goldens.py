@@ -128,7 +128,21 @@ def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, 
     out = {}
     for s in range(nsteps):
         b = fixtures.make_batch(B, T, H, seed + s, list(lens))
-        res = cpu_ref.gan_step(drive, opts, b, variant=variant, noise=b['noise'])
+
+        def d_side(mods, phon, s=s):
+            # What d_optimizer.step() consumes (train.py:210-211): the discriminators' gradients of dis_loss (R1
+            # double backward included), v_front's sync-loss contribution, and d dis_loss / d phon.
+            for mod in cpu_ref.D_NAMES + ('v_front',):
+                gn = 0.0
+                for pname, p in m[mod].named_parameters():
+                    if p.grad is None:
+                        continue
+                    idx = fixtures.sample_idx(p.numel(), 8, mod + '.' + pname)
+                    out['s%d:dgrad:%s:%s' % (s, mod, pname)] = np32(p.grad).reshape(-1)[idx]
+                    gn += float(p.grad.double().pow(2).sum())
+                out['s%d:dgradnorm:%s' % (s, mod)] = np.float64(gn ** 0.5)
+            out['s%d:dphon' % s] = np32(phon.grad)
+        res = cpu_ref.gan_step(drive, opts, b, variant=variant, noise=b['noise'], on_d_backward=d_side)
         for k in ('dis_loss', 'gen_loss', 'sync_loss', 'g_sync_loss', 'recon_loss', 'g_loss'):
             out['s%d:%s' % (s, k)] = np.float64(res[k])
         out['s%d:grad_p' % s] = np.array(res['grad_p'], dtype=np.float64)
@@ -150,16 +164,55 @@ def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, 
     print(name, {k: float(v) for k, v in out.items() if k.endswith('_loss')})
 
 
+def traj_case(rg, rv, name, variant='grid', B=2, T=20, H=112, lens=(20, 13), nsteps=8, seed=41, eps=1e-6, nper=4):
+    """Loss / output trajectory of the reference over several steps: run a on the fixture clips, runs b0..b{nper-1} on
+    clips moved by eps * N(0,1) (a different draw per run).  How far the b runs drift from a is the envelope the
+    network's own sensitivity allows a reimplementation whose arithmetic differs in the last bits; a test bounds its
+    own drift from a by a multiple of the widest of them."""
+    out = {}
+    for tag in ['a'] + ['b%d' % i for i in range(nper)]:
+        m = build_reference(rg, rv, 200)
+        for k in m:
+            m[k].train()
+        opts = cpu_ref.build_optimizers(m, amsgrad=(variant == 'grid'))
+        drive = dict(m)
+        drive['gen'] = RefGen(m['gen'])
+        for s in range(nsteps):
+            b = fixtures.make_batch(B, T, H, seed + s, list(lens))
+            if tag != 'a':
+                g = torch.Generator().manual_seed(seed + 1000 * (1 + int(tag[1:])) + s)
+                b['vid'] = b['vid'] + eps * torch.randn(b['vid'].shape, generator=g)
+            res = cpu_ref.gan_step(drive, opts, b, variant=variant, noise=b['noise'])
+            for k in ('dis_loss', 'gen_loss', 'sync_loss', 'g_sync_loss', 'recon_loss', 'g_loss'):
+                out['%s:%d:%s' % (tag, s, k)] = np.float64(res[k])
+            if tag == 'a':
+                out['a:%d:g3' % s] = np32(res['g3'])
+            else:
+                out['%s:%d:g3_l1' % (tag, s)] = np.float64(np.abs(np32(res['g3']) - out['a:%d:g3' % s]).mean())
+            print(name, tag, s, {k: round(float(res[k]), 6) for k in ('dis_loss', 'gen_loss', 'recon_loss')}, flush=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), B=B, T=T, H=H, lens=np.array(lens), seed=seed,
+                        wseed=200, nsteps=nsteps, variant=variant, eps=eps, nper=nper, **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     rg, rv = import_reference()
+    only = sys.argv[1:]
+    if only:            # e.g. `make_goldens.py step traj`: regenerate the step and trajectory fixtures only
+        if 'step' in only:
+            step_case(rg, rv, 'step_grid', 'grid')
+            step_case(rg, rv, 'step_lrs', 'lrs')
+        if 'traj' in only:
+            traj_case(rg, rv, 'traj_grid')
+        return
     forward_case(rg, rv, 'fwd_eval', train=False)
     forward_case(rg, rv, 'fwd_train', train=True)
     vfront_case(rg, rv, 'vfront_h104', 104)
     vfront_case(rg, rv, 'vfront_h128', 128)
     step_case(rg, rv, 'step_grid', 'grid')
     step_case(rg, rv, 'step_lrs', 'lrs')
+    traj_case(rg, rv, 'traj_grid')
 
 
 if __name__ == '__main__':

@@ -80,3 +80,70 @@ def measure_step(models, res, g, s, skip_grads=()):
     pdiff = np.concatenate(pdiff)
     mt['param_max'], mt['param_p90'] = float(pdiff.max()), float(np.percentile(pdiff, 90))
     return mt
+
+
+D_NAMES = ('dis1', 'dis2', 'dis3', 's_dis')
+
+
+def measure_d_side(models, dphon, g, s, names=D_NAMES):
+    """Deviations of the gradients d_optimizer.step() consumes (read between dis_loss.backward() and the optimizer
+    step, train.py:210-211) from the fixture's 'dgrad' keys: per network the relative L2 error over the sampled
+    entries and of the gradient norm, plus the relative L2 error of d dis_loss / d phon (the sync loss's way into
+    v_front).  The discriminators' gradients carry the R1 penalty's double backward."""
+    mt = {}
+    for mod in names:
+        got, want, gn = [], [], 0.0
+        for pname, p in models[mod].named_parameters():
+            key = 's%d:dgrad:%s:%s' % (s, mod, pname)
+            if key not in g.files:
+                continue
+            assert p.grad is not None, (mod, pname)
+            idx = fixtures.sample_idx(p.numel(), 8, mod + '.' + pname)
+            got.append(to_np(p.grad).reshape(-1)[idx])
+            want.append(g[key])
+            gn += float(p.grad.double().pow(2).sum())
+        got, want = np.concatenate(got), np.concatenate(want)
+        mt['dgrad_rel:' + mod] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        wn = float(g['s%d:dgradnorm:%s' % (s, mod)])
+        mt['dgradnorm_rel:' + mod] = abs(gn ** 0.5 - wn) / wn
+    if dphon is not None:
+        want = g['s%d:dphon' % s]
+        mt['dphon_rel'] = float(np.linalg.norm(to_np(dphon) - want) / np.linalg.norm(want))
+    return mt
+
+
+def check_d_side(models, dphon, g, s, grad_rel, names=D_NAMES):
+    mt = measure_d_side(models, dphon, g, s, names)
+    for k, v in mt.items():
+        assert v <= grad_rel, (s, k, v, mt)
+    return mt
+
+
+TRAJ_KEYS = ('dis_loss', 'gen_loss', 'recon_loss', 'sync_loss')
+
+
+def traj_deviation(run_step, g, nsteps=None, to_device=None):
+    """Drive run_step(batch) -> result dict over the trajectory fixture's batches.  Returns, per step, a dict
+    key -> (deviation from the reference's run a, envelope): relative loss deviations for TRAJ_KEYS and the mel-L1 of
+    g3 under 'g3_l1'.  The envelope of a quantity at step s is the largest distance between the reference's run a and
+    any of its runs b_i (clips 1e-6 apart) over steps 0..s: what the network's own sensitivity does to last-bit
+    differences."""
+    B, T, H = int(g['B']), int(g['T']), int(g['H'])
+    nper = int(g['nper'])
+    env = {k: 0.0 for k in TRAJ_KEYS + ('g3_l1',)}
+    out = []
+    for s in range(int(g['nsteps']) if nsteps is None else nsteps):
+        b = fixtures.make_batch(B, T, H, int(g['seed']) + s, list(g['lens']))
+        if to_device is not None:
+            b = to_device(b)
+        res = run_step(b)
+        d = {}
+        for k in TRAJ_KEYS:
+            a = float(g['a:%d:%s' % (s, k)])
+            for i in range(nper):
+                env[k] = max(env[k], abs(a - float(g['b%d:%d:%s' % (i, s, k)])) / max(1.0, abs(a)))
+            d[k] = (abs(float(res[k]) - a) / max(1.0, abs(a)), env[k])
+        env['g3_l1'] = max([env['g3_l1']] + [float(g['b%d:%d:g3_l1' % (i, s)]) for i in range(nper)])
+        d['g3_l1'] = (float(np.abs(to_np(res['g3']) - g['a:%d:g3' % s]).mean()), env['g3_l1'])
+        out.append(d)
+    return out

@@ -53,3 +53,20 @@ def test_single_channel_weight_gradient_workspace_query_and_argument_checks():
         assert f(ctypes.byref(b), 8, 8, 8, 1 << 40, 8, None, None) == -22, bad
     assert f(ctypes.byref(d), None, 8, 8, n, 8, None, None) == -22          # null input
     assert f(ctypes.byref(d), 8, 8, 8, n - 1, 8, None, None) == -22         # workspace one float short
+
+
+def test_gru_forward_step_rejects_hidden_sizes_it_cannot_slice():
+    """vca_gru_fwd_step_bf16 (nn.GRU step, visual_front.py:20,33-34) reads h_prev in 16-wide reduction slices: a hidden
+    size that is a multiple of 8 but not of 16 would read past a row, so it is refused (-22) before any GPU call."""
+    import __graft_entry__ as ge
+    ge.build()
+    from vcagan_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    f = L.vca_gru_fwd_step_bf16
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 12 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+    ptrs = [8] * 12
+    for H in (8, 24, 520):
+        assert f(3, 32, H, *ptrs, H, 8, 8, None) == -22, H
+    assert f(2, 32, 512, *ptrs, 512, 8, 8, None) == -22          # nsplit must be 1 or 3
+    assert f(3, 32, 512, *([8, 8] + [None] + [8] * 9), 512, 8, 8, None) == -22   # null weight

@@ -386,7 +386,8 @@ extern "C" int vca_gru_fwd_step_bf16(int nsplit, int B, int H, const float* hp0,
                                      const void* w1, const float* bhh0, const float* bhh1, const float* gi0,
                                      const float* gi1, float* hn0, float* hn1, float* out0, float* out1, int out_stride,
                                      float* save0, float* save1, void* stream) {
-  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && H > 0 && (H % 8) == 0 && w0 && w1 && gi0 && gi1);
+  // the kernel reads h_prev in whole 16-wide reduction slices (two float4 per lane): H must be a multiple of 16
+  VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && H > 0 && (H % 16) == 0 && w0 && w1 && gi0 && gi1);
   VCA_CHECK_ARG(hn0 && hn1 && out0 && out1 && save0 && save1 && out_stride >= H && (hp0 == nullptr) == (hp1 == nullptr));
   GruFwdArgs a;
   a.hp[0] = hp0; a.hp[1] = hp1;

@@ -229,6 +229,12 @@ _grad_conv = [False]   # True while a forward-type convolution is issued as part
                        # gradient, with a single product
 
 
+# 'mixed' runs the convolutions that differentiate an input-gradient node (the second-order terms of the R1 penalty in
+# the discriminators' backward pass) with one bf16 product, like every other gradient.  R1_SECOND_ORDER_SPLIT[0] = True
+# (VCA_R1_SPLIT=1) runs them with three: the A/B switch behind the measured D-side gradient figures.
+R1_SECOND_ORDER_SPLIT = [__import__('os').environ.get('VCA_R1_SPLIT') == '1']
+
+
 class use_precision:
     """Context manager: run the enclosed matrix-core convolutions at the given precision."""
 
@@ -309,8 +315,8 @@ def _conv_dgrad_raw(gy, w, cfg, res=None):
     return gx
 
 
-_wgrad_ws = {}          # (device, shape) -> [taps][Cin][Cout4] workspace, zero whenever no kernel is using it; shared by
-                        # every layer of that shape, so weight gradients must be issued on one stream at a time
+_wgrad_ws = {}          # (device, stream, shape) -> [taps][Cin][Cout4] workspace, zero whenever no kernel is using it;
+                        # shared by every layer of that shape issued on that stream (stream order serialises its users)
 _direct_grad = [False]  # set by direct_param_grad()
 
 
@@ -456,7 +462,7 @@ def _conv_wgrad_raw(x, gy, cfg, sink=None, bias_sink=None):
             dwp = _wgrad_own[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
         _wgrad_pending[key] = (dwp, sink, cout, cin, taps)
     else:
-        key = (x.device, shape)
+        key = (x.device, stream(), shape)
         dwp = _wgrad_ws.get(key)
         if dwp is None:
             dwp = _wgrad_ws[key] = torch.zeros(shape, device=x.device, dtype=torch.float32)
@@ -603,8 +609,8 @@ class ConvDgradFn(torch.autograd.Function):
         gy, w = ctx.saved_tensors
         cfg = ctx.cfg
         ggx = _c(ggx)
-        _exact_bwd[0] = torch.is_grad_enabled()
-        _grad_conv[0] = not torch.is_grad_enabled()
+        _exact_bwd[0] = torch.is_grad_enabled() or R1_SECOND_ORDER_SPLIT[0]
+        _grad_conv[0] = not _exact_bwd[0]
         ggy = ConvFn.apply(ggx, w, None, cfg) if ctx.needs_input_grad[0] else None
         _grad_conv[0] = False
         gw = None
@@ -627,9 +633,9 @@ class ConvWgradFn(torch.autograd.Function):
         x, gy = ctx.saved_tensors
         cfg = ctx.cfg
         ggw = _c(ggw)
-        _exact_bwd[0] = torch.is_grad_enabled()
+        _exact_bwd[0] = torch.is_grad_enabled() or R1_SECOND_ORDER_SPLIT[0]
         gx = ConvDgradFn.apply(gy, ggw, cfg) if ctx.needs_input_grad[0] else None
-        _grad_conv[0] = not torch.is_grad_enabled()
+        _grad_conv[0] = not _exact_bwd[0]
         ggy = ConvFn.apply(x, ggw, None, cfg) if ctx.needs_input_grad[1] else None
         _grad_conv[0] = False
         _exact_bwd[0] = False

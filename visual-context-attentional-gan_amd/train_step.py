@@ -28,16 +28,31 @@ _LOG_EPS = math.log(1e-5)
 # to the step's stream, also inside a captured graph: 80.5 -> 74.0 ms per step at B32 x T75 x 96x96.  VCA_D_STREAMS=0
 # (or train_step.D_STREAMS = False) keeps everything on one stream.
 D_STREAMS = __import__('os').environ.get('VCA_D_STREAMS', '1') != '0'
-# The full-resolution real mel is a leaf that both dis3 (on its stream) and the sync discriminator (on the step's
-# stream) differentiate: autograd synchronises the two producers itself and warns that it had to.
 # Branch -> stream: dis3 (80x300 mels, four down-sampling blocks: more work than dis1 and dis2 together) has a stream to
 # itself and is issued first, dis1 and dis2 share one, a fourth branch (the ASR scorer of the multi-task step) gets its
 # own.  Measured against one stream per discriminator: 73.1 vs 73.5 ms per step, with one stream fewer (a process has
 # four hardware queues on this part, and the collectives of a data-parallel run bring their own stream).
 _BRANCH_STREAM = {0: 0, 1: 0, 2: 1, 3: 2}
 _BRANCH_ORDER = (2, 3, 0, 1)
-if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
-    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+class _quiet_leaf_streams:
+    """Around the step's two backward calls, and only with D_STREAMS: the full-resolution real mel is a leaf that both
+    dis3 (on its stream) and the sync discriminator (on the step's stream) differentiate; autograd synchronises the two
+    producers itself and warns that it had to.  The process-wide switch is restored on exit, so the diagnostic stays
+    on for everything else."""
+
+    def __enter__(self):
+        self.prev = None
+        get = getattr(torch._C, '_warn_on_accumulate_grad_stream_mismatch', None)
+        if D_STREAMS and get is not None and hasattr(torch.autograd.graph,
+                                                     'set_warn_on_accumulate_grad_stream_mismatch'):
+            self.prev = bool(get())
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(self.prev)
 
 
 def build_models(temp=1.0, device=None):
@@ -225,7 +240,7 @@ class GanStep:
         hd.add(ops.HEAD_SUM, sync, ((1, 1.0), (0, 1.0 if self.variant == 'grid' else 0.5)))
         out = hd.run(5)
         self._zero(D_NAMES)
-        with ops.direct_param_grad():
+        with ops.direct_param_grad(), _quiet_leaf_streams():
             out.backward(self._onehot(5, 0, out.device))
             self._join_dis()
         self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
@@ -286,7 +301,7 @@ class GanStep:
         # No gradient buffer needs clearing here: the generator side was cleared at the start of the step and the D
         # phase's backward stops at the detached generator outputs and at phon_d, so it has added nothing to gen /
         # post; the discriminators' parameters take no gradient in this phase.
-        with ops.direct_param_grad():
+        with ops.direct_param_grad(), _quiet_leaf_streams():
             torch.autograd.backward([out, phon], [self._onehot(out.numel(), 0, out.device), st['phon_d'].grad])
             self._join_dis()
         for p in d_params:
