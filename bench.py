@@ -209,6 +209,10 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
+        # The exchange must be RCCL on device buffers: any other backend stages 400 MB per step through the host
+        # (grad_exchange.GradExchange) and the run would measure PCIe.
+        if dist.get_backend() != 'nccl':
+            sys.exit('bench.py: the gradient exchange needs the nccl (RCCL) backend, got %r' % dist.get_backend())
 
     import vcagan_amd  # noqa: F401
     from vcagan_amd import ops, train_step
@@ -243,10 +247,11 @@ def main():
                                              'device',
                                              segmented=True if os.environ.get('VCA_BENCH_SEGMENTED') == '1' else None,
                                              text=text, text_len=text_len)
-        except Exception as e:       # capture not possible on this stack: fall back to eager launches
-            print('graph capture failed, running eagerly: %r' % (e,), file=sys.stderr)
-            graphed = None
-            torch.cuda.synchronize()
+        except Exception as e:
+            # An eager step is a different benchmark (several thousand launches issued from Python): never time it
+            # under the headline's name.  --no-graph asks for it explicitly and is labelled in `launch`.
+            print('bench.py: graph capture failed: %r' % (e,), file=sys.stderr)
+            sys.exit(3)
 
     feed = data
     if args.host_inputs and graphed is not None:
@@ -273,6 +278,8 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if use_dist:                       # HIP events around the two all-reduces of every timed step
+        step.d_exchange.timed, step.g_exchange.timed = [], []
     if os.environ.get('VCA_BENCH_CHECK') == '1':
         for n, m in models.items():
             print('check', n, 'params finite', all(bool(torch.isfinite(p).all()) for p in m.parameters()),
@@ -318,6 +325,14 @@ def main():
             'ref_algorithmic_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
             'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
         }
+        if use_dist:
+            ex = [sum(a.elapsed_time(b) for a, b in e.timed) / max(1, args.steps)
+                  for e in (step.d_exchange, step.g_exchange)]
+            res['exchange_ms'] = {'d_side': round(ex[0], 3), 'g_side': round(ex[1], 3),
+                                  'bytes': [int(sum(g.numel() for g in e.gflats) * 4)
+                                            for e in (step.d_exchange, step.g_exchange)],
+                                  'note': 'per step on rank 0, HIP events on the compute stream around each side\'s '
+                                          'mean all-reduce (issued between the per-phase graphs, nothing overlapped)'}
         res['roofline'] = roofline_probe(device, dtype)
         res['dtype_note'] = DTYPE_NOTE.get(dtype, dtype)
         if world == 1 and not lrs:

@@ -74,3 +74,34 @@ def test_discriminator_streams_change_nothing(prec, graph):
             assert _rel(g2[k], g1[k]) <= (5e-3 if k == 'd' else 5e-2), (k, _rel(g2[k], g1[k]))
     for k in p1:
         assert float((p1[k] - p2[k]).abs().max()) <= 6.1e-4, k       # at most three steps of lr = 1e-4 each, both ways
+
+
+@gpu
+def test_helper_streams_inside_the_discriminators():
+    """generator.HEAD_STREAMS (conditional head on a helper stream forked from the stream its discriminator runs on):
+    eagerly it changes nothing, with or without the discriminators' own streams; under capture it is allowed only
+    when the helpers fork from the capture's origin stream (D_STREAMS off), and GraphedStep refuses the combination
+    that would fork and join on a forked stream - the pattern that makes this runtime's hipStreamEndCapture crash the
+    process - before it captures anything."""
+    from vcagan_amd import train_step
+    from vcagan_amd.models import generator as G
+    base, g0, _ = _run(True, 'mixed', False)
+    old = G.HEAD_STREAMS
+    G.HEAD_STREAMS = True
+    try:
+        for streams, graph in ((True, False), (False, False), (False, True)):
+            got, g1, _ = _run(streams, 'mixed', graph)
+            if not graph:
+                for k in LOSSES:
+                    assert abs(got[0][k] - base[0][k]) <= 2e-5 * max(1.0, abs(base[0][k])), (streams, k)
+                assert _rel(g1['d'], g0['d']) <= 5e-3 and _rel(g1['g'], g0['g']) <= 5e-2
+            else:
+                for o in got:
+                    assert all(abs(o[k]) < 1e4 for k in LOSSES) and torch.isfinite(o['g3']).all()
+                # the first replay is update 1 (the capture's warm-up step was update 0)
+                for k in LOSSES:
+                    assert abs(got[0][k] - base[1][k]) <= 3e-3 * max(1.0, abs(base[1][k])), (k, got[0][k], base[1][k])
+        with pytest.raises(RuntimeError, match='forked stream'):
+            _run(True, 'mixed', True)
+    finally:
+        G.HEAD_STREAMS = old

@@ -22,14 +22,23 @@ class GradExchange:
         forced = (force or os.environ.get('VCA_FORCE_EXCHANGE') == '1') and ready
         self.active = self.world > 1 or forced
         self.avg = ready and dist.get_backend(group) == 'nccl'
+        self.timed = None     # a list: reduce() appends a (start, end) pair of device events per call (bench.py)
 
     def reduce(self):
         if not self.active:
             return
         if self.avg:
+            ev = None
+            if self.timed is not None:
+                import torch
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             works = [dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=True) for g in self.gflats]
             for w in works:
-                w.wait()
+                w.wait()                 # the compute stream waits for the collective's stream; the host does not
+            if ev is not None:
+                ev[1].record()
+                self.timed.append(ev)
             return
         for g in self.gflats:
             h = g.cpu() if g.is_cuda else g

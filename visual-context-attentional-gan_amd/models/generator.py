@@ -16,6 +16,14 @@ from .resnet import BasicBlock
 _RSQRT2 = 1.0 / math.sqrt(2.0)
 SUBPIXEL_UPSAMPLE = True   # False: 5x5 convolution reading through the nearest x2 upsample (the reference's formulation)
 TILED_INPUT = True     # False: build the (B, 20, T, 640) decoder input explicitly (the reference's formulation)
+# True: a discriminator's conditional head runs on a helper stream beside its unconditional head (one helper per calling
+# stream).  Off by default (no gain measured).  It must not be combined with a graph capture in which the discriminator
+# itself runs on a forked stream: a forked stream that forks a helper and waits for it again (fork and join on a stream
+# other than the capture's origin) makes hipStreamEndCapture of the ROCm 7.0 runtime crash the process (host-side
+# segmentation fault; tools/probes/capture_streams_probe.py reproduces it with three streams and four torch kernels:
+# `1 1 1`).  Forks from the origin stream, nested forks joined only to the origin, and waits between forked siblings all
+# capture fine.  train_step.GraphedStep refuses the combination before it starts capturing.
+HEAD_STREAMS = __import__('os').environ.get('VCA_D_HEAD_STREAMS') == '1'
 
 
 def _conv(x, m, ups=0, **kw):
@@ -325,15 +333,30 @@ class Discriminator(nn.Module):
         for blk in list(self.main)[1:]:
             h = blk(h)
         ah = ops.leaky(h)
-        u = _conv(ah, self.uncond[1])
-        u = ops.linear(ops.spatial_mean(ops.leaky(u)), self.uncond[4].weight, self.uncond[4].bias)
-        cvec = ops.WindowMeanFn.apply(c.reshape(B * 512, 1, c.size(2), 1), 1, c.size(2)).view(B, 512)   # c.mean(2)
-        if TILED_INPUT:
-            o = self._cond_conv(ah, ops.leaky(cvec))
+
+        def uncond():
+            u = _conv(ah, self.uncond[1])
+            return ops.linear(ops.spatial_mean(ops.leaky(u)), self.uncond[4].weight, self.uncond[4].bias)
+
+        def cond():
+            cvec = ops.WindowMeanFn.apply(c.reshape(B * 512, 1, c.size(2), 1), 1, c.size(2)).view(B, 512)  # c.mean(2)
+            if TILED_INPUT:
+                o = self._cond_conv(ah, ops.leaky(cvec))
+            else:
+                o = _conv(ops.leaky(ops.concat2(h, cvec, B, 5, f_len)), self.cond[1])
+            o = _conv(ops.leaky(o), self.cond[3])
+            return ops.linear(ops.spatial_mean(ops.leaky(o)), self.cond[6].weight, self.cond[6].bias)
+
+        if HEAD_STREAMS and x.is_cuda:
+            cur = torch.cuda.current_stream()
+            helper = ops.side_stream(('dis_head', cur.cuda_stream))
+            helper.wait_stream(cur)
+            with torch.cuda.stream(helper):
+                o = cond()
+            u = uncond()
+            cur.wait_stream(helper)
         else:
-            o = _conv(ops.leaky(ops.concat2(h, cvec, B, 5, f_len)), self.cond[1])
-        o = _conv(ops.leaky(o), self.cond[3])
-        o = ops.linear(ops.spatial_mean(ops.leaky(o)), self.cond[6].weight, self.cond[6].bias)
+            u, o = uncond(), cond()
         return u.view(B, -1), o.view(B, -1)
 
 

@@ -336,6 +336,13 @@ class GraphedStep:
     def __init__(self, step, mel, spec, vid, vid_len, noise='device', warmup=2, segmented=None, text=None,
                  text_len=None):
         assert warmup >= 1, 'one uncaptured step must run first: lazy state and the scratch arena settle there'
+        if D_STREAMS and G.HEAD_STREAMS:
+            # fork + join on a forked stream: hipStreamEndCapture of this runtime crashes the process (see
+            # models/generator.py HEAD_STREAMS); every fork of a captured step must start from and return to the
+            # capture's origin stream
+            raise RuntimeError('a captured step cannot run the discriminators on streams of their own (D_STREAMS) and '
+                               'fork helper streams from those streams (generator.HEAD_STREAMS): the HIP runtime '
+                               'crashes when a capture joins a helper back into a forked stream')
         self.step = step
         dev = mel.device
         self.device_noise = isinstance(noise, str)
