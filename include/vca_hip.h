@@ -152,12 +152,15 @@ int vca_pack_weight_bf16_batch(const vca_pack_desc* table, int ndesc, int total_
 
 /* Conv3d stem of the visual front-end (nn.Conv3d(1, 64, (5,7,7), (1,2,2), (2,3,3), bias=False),
  * visual_front.py:11) in split-bf16: x is the single-channel video [B][T][H][W], y the channels-last feature map
- * [B][T][OH][OW][64] with OH = (H-1)/2+1.  wpack (2*64*296 bf16 = 75,776 bytes) is written by vca_stem_pack_weight
- * from the parameter's [64][1][5][7][7] layout.  stats (128 floats, zeroed by the caller, may be NULL) receives the
- * per-channel sum and sum of squares of y for the BatchNorm3d that follows (visual_front.py:12). */
+ * [B][T][OH][OW][64] with OH = (H-1)/2+1.  wpack (vca_stem_pack_bytes() bytes, 16-byte aligned: the hi/lo bf16
+ * register fragments of every reduction step) is written by vca_stem_pack_weight from the parameter's
+ * [64][1][5][7][7] layout.  stats ([stat_slots][2][64] floats, zeroed by the caller, may be NULL) receives partial
+ * per-channel sums and sums of squares of y for the BatchNorm3d that follows (visual_front.py:12): the statistic is
+ * the total over the slots (vca_bn_finalize_f32 takes the slot count). */
+long long vca_stem_pack_bytes(void);
 int vca_stem_pack_weight(const float* w, void* wpack, void* stream);
 int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, const void* wpack, float* y,
-                      float* stats, void* stream);
+                      float* stats, int stat_slots, void* stream);
 /* Patch form of the clip for the stem's weight gradient (visual_front.py:11 backward): xp is
  * [B][T][OH*OW][64] with channel kh*8+kw = clip[b][t][2*oy+kh-3][2*ox+kw-3] (zero outside the clip and for kh or
  * kw = 7), over which the 5x7x7 stride-(1,2,2) convolution is a 5-tap convolution along t with 64 input channels,

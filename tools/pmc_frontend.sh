@@ -1,15 +1,16 @@
 #!/bin/bash
 # Counter passes over the front-end / attention probe (separate rocprofv3 --pmc runs, one counter group each) plus one
-# kernel-trace pass for the durations.   usage: tools/pmc_frontend.sh OUTDIR
-set -e
+# kernel-trace pass for the durations.   usage: tools/pmc_frontend.sh OUTDIR [probe.py]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/$1
+PROBE=${2:-tools/probes/frontend_probe.py}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o vm -- python3 $R/tools/probes/frontend_probe.py > $OUT/kt.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o vm -- python3 $R/$PROBE > $OUT/kt.log 2>&1 || exit 1
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o vm -- python3 $R/tools/probes/frontend_probe.py > $OUT/p$i.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o vm -- python3 $R/$PROBE > $OUT/p$i.log 2>&1 || exit 1
 done

@@ -14,7 +14,7 @@ B, T, H = 32, 75, 96
 dev = torch.device('cuda', 0)
 x = torch.randn(B, T, H, H, 1, device=dev)
 w = torch.nn.Parameter(torch.randn(64, 1, 5, 7, 7, device=dev) * 0.05)
-nbytes = x.numel() * 4 + 75776 + B * T * (H // 2) ** 2 * 64 * 4
+nbytes = x.numel() * 4 + 73728 + B * T * (H // 2) ** 2 * 64 * 4
 flops = 2.0 * B * T * (H // 2) ** 2 * 64 * 245
 for prec in ('bf16x3', 'bf16', 'fp32'):
     ops.set_precision(prec)

@@ -72,7 +72,8 @@ _SIGS = {
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_pack_weight_bf16_batch': ([_P, _I, _I, _I, _P], _I),
     'vca_stem_pack_weight': ([_P, _P, _P], _I),
-    'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
+    'vca_stem_pack_bytes': ([], _LL),
+    'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], _I),
     'vca_stem_patches_f32': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_colstats_f32': ([_I, _I, _P, _P, _P], _I),
     'vca_bn_finalize_f32': ([_I, _F, _P, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),

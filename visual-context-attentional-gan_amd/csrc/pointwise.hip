@@ -453,20 +453,28 @@ __global__ __launch_bounds__(THR) void maxpool3_fwd_kernel(int N, int H, int W, 
 
 // y = maxpool3x3s2(act(x*scale + shift)) in one pass over x (visual_front.py:12-14: BatchNorm3d -> PReLU ->
 // MaxPool3d((1,3,3),(1,2,2),(0,1,1))): the activated full-resolution map is never written.
+// Neighbouring windows share input rows and columns.  Workgroups are dealt round-robin over the 8 XCDs, each with an
+// L2 of its own, so the work is laid out per image: all workgroups of an image have the same blockIdx % 8 and its
+// shared rows are fetched into one L2 once instead of into several.
 __global__ __launch_bounds__(THR) void affine_act_pool3_kernel(int N, int H, int W, int OH, int OW, int C, int act,
                                                                float slope, const float* __restrict__ x,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ alpha,
-                                                               float* __restrict__ y, unsigned char* __restrict__ idx) {
+                                                               float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                               int wg_per_img) {
   const int C4 = C >> 2;
-  const size_t total = (size_t)N * OH * OW * C4;
-  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < total; i += (size_t)gridDim.x * THR) {
-    const int c = (int)(i % C4) * 4;
-    size_t r = i / C4;
-    const int ow = r % OW; r /= OW;
-    const int oh = r % OH;
-    const int n = r / OH;
+  const int per_img = OH * OW * C4;
+  const int xcd = blockIdx.x & 7, njobs = ((N + 7) >> 3) * wg_per_img;
+  for (int job = blockIdx.x >> 3; job < njobs; job += gridDim.x >> 3) {
+    const int n = (job / wg_per_img) * 8 + xcd;
+    const int r0 = (job % wg_per_img) * THR + threadIdx.x;
+    if (n >= N || r0 >= per_img) continue;
+    const size_t i = (size_t)n * per_img + r0;
+    const int c = (r0 % C4) * 4;
+    int r = r0 / C4;
+    const int ow = r % OW;
+    const int oh = r / OW;
     const float4 sc = ld4(scale + c), sh = ld4(shift + c);
     float sl[4] = {slope, slope, slope, slope};
     if (act == VCA_ACT_PRELU) {
@@ -699,7 +707,11 @@ extern "C" int vca_affine_act_pool3_fwd_f32(int N, int H, int W, int C, const fl
   VCA_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && x && scale && shift && y && idx);
   VCA_CHECK_ARG(act >= 0 && act <= 4 && (act != VCA_ACT_PRELU || alpha));
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(affine_act_pool3_kernel, dim3(grid_for((size_t)N * OH * OW * (C / 4))), dim3(THR), 0,
-                     (hipStream_t)stream, N, H, W, OH, OW, C, act, slope, x, scale, shift, alpha, y, idx);
+  VCA_CHECK_ARG((long long)OH * OW * (C / 4) < (1ll << 30));
+  const int wg_per_img = (OH * OW * (C / 4) + THR - 1) / THR;
+  long long g8 = (long long)((N + 7) / 8) * wg_per_img;      // jobs per XCD lane
+  if (g8 > 256) g8 = 256;
+  hipLaunchKernelGGL(affine_act_pool3_kernel, dim3((unsigned)(8 * g8)), dim3(THR), 0, (hipStream_t)stream, N, H, W, OH,
+                     OW, C, act, slope, x, scale, shift, alpha, y, idx, wg_per_img);
   return vca_launch_status();
 }

@@ -1,17 +1,24 @@
 // Conv3d stem of the visual front-end (visual_front.py:11): 1 -> 64 channels, 5x7x7 taps, stride (1,2,2), padding
 // (2,3,3), on single-channel video [B][T][H][W] -> channels-last [B][T][H/2][W/2][64], split-bf16 MFMA.
 //
-// One persistent workgroup (8 waves) walks patches of 16x16 output pixels of one frame.  The packed weights (hi/lo bf16,
-// [64][35 (kt,kh) rows x 8 kw slots], 74 KiB) are loaded into LDS once per workgroup; per patch the fp32 input halo
-// (5 frames x 37 rows x 40 columns) is prefetched into registers under the previous patch's MFMAs and split into
-// hi/lo bf16 ONCE when it is written to LDS (each halo element is used by up to 64 (pixel, tap) pairs; converting
-// inside the MFMA loop cost a fifth of the kernel's VALU instructions).  The reduction index is laid out as
-// (kt, kh, kw') with kw' = kw + 1 in 0..7 (slot 0 has zero weight), so the 8 reduction elements one MFMA lane
-// supplies are 8 CONTIGUOUS values of a halo row (x = 2*ox - 4 + kw'): two 8-byte LDS reads per hi and lo image.
-// The row offset 2*tx is only 4-byte aligned for odd tx, so every image is kept twice, the second copy shifted by
-// two elements: even tx read copy 0, odd tx copy 1, both 8-byte aligned.  No im2col image is ever materialised.  Per-channel sum / sum-of-squares of the outputs (for
-// the following train-mode BatchNorm3d, visual_front.py:12) are accumulated in registers across the walk and added
-// to `stats` once per workgroup.
+// A workgroup (4 waves) owns one 16x16 patch of output pixels of one clip and WALKS a chunk of consecutive frames.
+// LDS holds a ring of five input-frame halos (37 rows x 40 columns each, hi/lo bf16): per output frame one new input
+// frame is staged (its raw fp32 values were fetched into registers under the previous frame's MFMAs and are split into
+// hi/lo ONCE when written to LDS) and the five temporal taps read the ring, so a frame is fetched once per patch and
+// chunk instead of once per temporal tap.  The weights never touch LDS: a wave owns 32 of the 64 output channels for
+// half of the patch and keeps their hi/lo bf16 fragments for all 18 reduction steps in registers (144 VGPRs), which
+// leaves room for two workgroups per CU (74 KiB of LDS each).
+//
+// The reduction index is laid out as (kt, kh, kw') with kw' = kw + 1 in 0..7 (slot 0 has zero weight), so the 8
+// reduction elements one MFMA lane supplies are 8 CONTIGUOUS values of a halo row (x = 2*ox - 4 + kw'): two 8-byte LDS
+// reads per hi and lo image.  The row offset 2*tx is only 4-byte aligned for odd tx, so every image is kept twice, the
+// second copy shifted by two elements: even tx read copy 0, odd tx copy 1, both 8-byte aligned.  The 32 lanes that
+// share an LDS cycle are the 16 x 2 pixels of a tile reading the same halo row; with a row pitch of 48 elements (the
+// second pixel row lands 48 dwords further) and copy 1 placed 30 dwords (mod 64) behind copy 0 the four 16-dword runs
+// they touch tile the 64 banks exactly.  No im2col image is ever materialised.  The MFMAs take the pixels as the row
+// operand, so a lane ends up with ONE channel of 16 pixels: a store instruction writes whole 128-byte lines and the
+// batch-norm sums are two registers per lane.  Per-channel sum / sum-of-squares of the outputs (for the following train-mode BatchNorm3d, visual_front.py:12) are
+// accumulated in registers across the walk and added to one of `stat_slots` partial buffers once per workgroup.
 #include "common.h"
 
 namespace {
@@ -20,233 +27,291 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CO = 64, KT = 5, KH = 7, KW = 7;
 constexpr int NQ = KT * KH;          // 35 (kt,kh) rows of 8 kw slots
-constexpr int KPAD = 288;            // 36 rows * 8 (multiple of 32)
-constexpr int WROW = 296;            // bf16 elements per packed weight row (592 B: conflict-free 16-byte reads)
-constexpr int PH = 16, PW = 16;      // output patch (8 waves x 32 pixels)
-constexpr int NTHR = 512;
+constexpr int NSTEP = 18;            // reduction steps of 16 (two rows each; row 35 is padding)
+constexpr int PH = 16, PW = 16;      // output patch
+constexpr int NTHR = 256;
 constexpr int HR = 2 * (PH - 1) + KH;  // 37 halo rows
-constexpr int HC = 40;               // halo columns (2*15 + 7 + 1 = 38, padded)
-constexpr int HALO = KT * HR * HC;   // 7400 elements
-constexpr int HC2 = 44;              // bf16 row pitch of the LDS images (40 columns + 2 shift, multiple of 4)
-constexpr int HIMG = KT * HR * HC2;  // elements of one LDS halo image
+constexpr int HC = 40;               // halo columns staged (2*15 + 7 + 1 = 38, in groups of 4)
+constexpr int HP = 48;               // bf16 row pitch of an LDS image (24 dwords)
+constexpr int IMG = 1852;            // elements per image: 37 * 48 = 1776, padded to 926 dwords = 30 (mod 64)
+constexpr int NRING = 5;
+constexpr int TCHUNK = 15;           // output frames per workgroup (+4 frames staged without output)
+constexpr int WFRAG_U4 = 2 * NSTEP * 2 * 64;   // uint4 entries of the packed weight fragments
 
+// dst[channel half][step][hi|lo][lane] = the 8 bf16 a lane feeds as the row operand of that step's MFMA:
+// lane (r = lane & 31, h = lane >> 5) holds channel 32*half + r, reduction row q = 2*step + h, slots kw' = 0..7
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ dst) {
-  // dst[2][64][WROW]: hi image then lo image
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= CO * WROW) return;
-  const int co = i / WROW, k = i - co * WROW;
-  float v = 0.f;
-  const int q = k >> 3, s = k & 7;
-  if (q < NQ && s >= 1) v = w[(co * NQ + q) * KW + (s - 1)];
-  const __bf16 h = (__bf16)v;
-  dst[i] = h;
-  dst[CO * WROW + i] = (__bf16)(v - (float)h);
+  if (i >= 2 * NSTEP * 64) return;
+  const int lane = i & 63, s = (i >> 6) % NSTEP, half = i / (64 * NSTEP);
+  const int co = half * 32 + (lane & 31), q = 2 * s + (lane >> 5);
+  __bf16* hi = dst + ((size_t)((half * NSTEP + s) * 2 + 0) * 64 + lane) * 8;
+  __bf16* lo = dst + ((size_t)((half * NSTEP + s) * 2 + 1) * 64 + lane) * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = 0.f;
+    if (q < NQ && j >= 1) v = w[(co * NQ + q) * KW + (j - 1)];
+    const __bf16 hv = (__bf16)v;
+    hi[j] = hv;
+    lo[j] = (__bf16)(v - (float)hv);
+  }
 }
 
+union Frag {
+  bf16x8 v;
+  unsigned long long d[2];
+};
+
+// One fragment (8 bf16 of the hi image and, with three products, of the lo image 2 * IMG elements further) as 8-byte
+// LDS reads; addr is the byte address of the hi fragment.
+template <int NSPLIT>
+__device__ __forceinline__ void lds_read_frag(unsigned addr, Frag& h, Frag& l) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(h.d[0]) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(h.d[1]) : "v"(addr));
+  if (NSPLIT == 3) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(l.d[0]) : "v"(addr), "n"(2 * IMG * 2));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(l.d[1]) : "v"(addr), "n"(2 * IMG * 2 + 8));
+  }
+}
+
+// Wait until the fragment's reads have landed while the reads of the BEHIND fragments requested after it (2 or 4
+// instructions each) stay in flight.  LDS operations complete in order, so "all but the youngest N" covers it; the
+// wait names the fragment's registers so that the MFMAs that consume them depend on it.
+template <int NSPLIT, int BEHIND>
+__device__ __forceinline__ void lds_wait_frag(Frag& h, Frag& l) {
+  constexpr int N = BEHIND * (NSPLIT == 3 ? 4 : 2);
+  if (NSPLIT == 3)
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(h.d[0]), "+v"(h.d[1]), "+v"(l.d[0]), "+v"(l.d[1]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(h.d[0]), "+v"(h.d[1]) : "n"(N));
+}
+
+constexpr int AHEAD = 2;             // fragment reads are issued this many reduction steps ahead of their MFMAs
+
 // VEC: W is a multiple of 4, so that a group of 4 halo columns (the halo starts at a multiple of 4) is one aligned
-// float4 that lies entirely inside or outside the frame: a quarter of the loads, bounds tests and LDS stores.
+// float4 that lies entirely inside or outside the frame.
 template <int NSPLIT, bool VEC>
-__global__ __launch_bounds__(NTHR) void stem_fwd_kernel(int B, int T, int H, int W, int OH, int OW,
-                                                       const float* __restrict__ x, const __bf16* __restrict__ wp,
-                                                       float* __restrict__ y, float* __restrict__ stats,
-                                                       int tiles_y, int tiles_x, int npatch) {
+__global__ __launch_bounds__(NTHR, 2) void stem_fwd_kernel(int B, int T, int H, int W, int OH, int OW,
+                                                          const float* __restrict__ x,
+                                                          const uint4* __restrict__ wfrag, float* __restrict__ y,
+                                                          float* __restrict__ stats, int stat_slots, int tiles_y,
+                                                          int tiles_x, int tchunks, int nunits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* w_hi = reinterpret_cast<__bf16*>(smem);
-  __bf16* w_lo = w_hi + CO * WROW;
-  // halo images: [copy 0 | copy 1 (shifted by 2)] x [hi | lo]
-  __bf16* h_hi = reinterpret_cast<__bf16*>(smem + (NSPLIT == 3 ? 2 : 1) * CO * WROW * 2);
-  __bf16* h_lo = h_hi + 2 * HIMG;
+  constexpr int NIMG = NSPLIT == 3 ? 4 : 2;       // [hi copy 0 | hi copy 1 | lo copy 0 | lo copy 1]
+  constexpr int SLOT = NIMG * IMG;                // elements per ring slot
+  __bf16* ring = reinterpret_cast<__bf16*>(smem);
+  const unsigned ring_addr = (unsigned)(uintptr_t)smem;      // LDS byte address (the low half of the flat address)
+
+  // Work unit of this workgroup.  Consecutive workgroups are dealt round-robin over the 8 XCDs, so units that share
+  // input (neighbouring patches and chunks of one clip) are given to workgroups of equal blockIdx % 8: one L2.
+  const int per = (int)gridDim.x >> 3;
+  const int unit = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (unit >= nunits) return;
+  int u = unit;
+  const int tc = u % tchunks; u /= tchunks;
+  const int tix = u % tiles_x; u /= tiles_x;
+  const int tiy = u % tiles_y;
+  const int b = u / tiles_y;
+  const int t0 = tc * TCHUNK, t1 = min(T, t0 + TCHUNK);
+  const int oy0 = tiy * PH, ox0 = tix * PW;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = wave & 1, prow0 = (wave >> 1) * 8;     // channel half; first patch row of this wave's 8 rows
   const int lr = lane & 31, lh = lane >> 5;
+  const int tx = lr & 15, tyl = lr >> 4;
 
-  for (int i = tid; i < (NSPLIT == 3 ? 2 : 1) * CO * WROW / 8; i += NTHR)
-    reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(wp)[i];
+  // weight fragments of this wave's 32 channels: registers for the whole walk
+  bf16x8 wh[NSTEP], wl[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    union { uint4 u; bf16x8 v; } c;
+    c.u = wfrag[((half * NSTEP + s) * 2 + 0) * 64 + lane];
+    wh[s] = c.v;
+    if (NSPLIT == 3) {
+      c.u = wfrag[((half * NSTEP + s) * 2 + 1) * 64 + lane];
+      wl[s] = c.v;
+    }
+  }
 
-  // this lane's output pixel inside the patch (GEMM row wave*32 + lr)
-  const int ty = wave * 2 + (lr >> 4), tx = lr & 15;
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-
-  // halo staging plan of this thread: NL items i = tid + NTHR*j (one element, or 4 consecutive columns with VEC),
-  // decomposed once into (kt, row, column)
-  constexpr int EPI = VEC ? 4 : 1;                        // elements per item
-  constexpr int NITEM = HALO / EPI;
-  constexpr int NL = (NITEM + NTHR - 1) / NTHR;
-  int plan[NL];
+  // halo staging plan of this thread: items i = tid, tid + 256 (a group of 4 columns of one halo row)
+  constexpr int NITEM = HR * (HC / 4);            // 370
+  constexpr int NL = (NITEM + NTHR - 1) / NTHR;   // 2
+  const int y0 = 2 * oy0 - 3, x0 = 2 * ox0 - 4;
+  int lds_o[NL];
+  int goff[NL];                                   // element offset inside a frame, or -1 (a frame holds < 2^31 elements)
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     const int i = tid + NTHR * j;
-    const int c = (i % (HC / EPI)) * EPI, rr = i / (HC / EPI);
-    plan[j] = i < NITEM ? ((rr / HR) | ((rr % HR) << 8) | (c << 16)) : -1;
+    const int row = i / (HC / 4), c4 = (i - row * (HC / 4)) * 4;
+    const int iy = y0 + row, ix = x0 + c4;
+    lds_o[j] = i < NITEM ? row * HP + c4 : -1;
+    bool ok = i < NITEM && iy >= 0 && iy < H;
+    if (VEC) ok = ok && ix >= 0 && ix < W;
+    goff[j] = ok ? iy * W + ix : -1;
   }
-  float hv[NL][EPI];
-  auto issue = [&](int patch) {   // all loads of the patch's halo are issued back to back (kept in flight)
-    int r = patch;
-    const int tix = r % tiles_x; r /= tiles_x;
-    const int tiy = r % tiles_y; r /= tiles_y;
-    const int t = r % T;
-    const int b = r / T;
-    const int y0 = 2 * tiy * PH - 3, x0 = 2 * tix * PW - 4;
+  const float* xb = x + (size_t)b * T * H * W;
+  const size_t fstride = (size_t)H * W;
+  float hv[NL][4];
+  auto fetch = [&](int f) {       // raw fp32 values of input frame f into registers (zeros outside the clip)
+    const bool fin = f >= 0 && f < T;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const int pl = plan[j];
-      const int it = t + (pl & 255) - 2, iy = y0 + ((pl >> 8) & 255), ix = x0 + (pl >> 16);
-      const bool ok = pl >= 0 && it >= 0 && it < T && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      if constexpr (VEC) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(x + (((size_t)b * T + it) * H + iy) * W + ix);
-        hv[j][0] = v.x; hv[j][1] = v.y; hv[j][2] = v.z; hv[j][3] = v.w;
-      } else {
-        hv[j][0] = ok ? x[(((size_t)b * T + it) * H + iy) * W + ix] : 0.f;
+      hv[j][0] = hv[j][1] = hv[j][2] = hv[j][3] = 0.f;
+      if (fin && goff[j] >= 0) {
+        const float* p = xb + (size_t)f * fstride + goff[j];
+        if constexpr (VEC) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          hv[j][0] = v.x; hv[j][1] = v.y; hv[j][2] = v.z; hv[j][3] = v.w;
+        } else {
+          const int ix = x0 + (lds_o[j] % HP);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ix + e >= 0 && ix + e < W) hv[j][e] = p[e];
+        }
       }
     }
   };
-
-  if ((int)blockIdx.x < npatch) issue(blockIdx.x);
-  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-    int r = patch;
-    const int tix = r % tiles_x; r /= tiles_x;
-    const int tiy = r % tiles_y; r /= tiles_y;
-    const int t = r % T;
-    const int b = r / T;
-    const int oy0 = tiy * PH, ox0 = tix * PW;
-    __syncthreads();   // previous patch fully consumed (and the weights are in place on the first pass)
+  auto stage = [&](int f) {       // split the registers into hi/lo and write both copies of frame f's ring slot
+    __bf16* base = ring + ((f + 2 * NRING) % NRING) * SLOT;
 #pragma unroll
     for (int j = 0; j < NL; ++j)
-      if (plan[j] >= 0) {
-        const int pl = plan[j];
-        const int c = pl >> 16, rr = (pl & 255) * HR + ((pl >> 8) & 255);
-        const int o = rr * HC2 + c;
-        if constexpr (VEC) {
-          // o is a multiple of 4 elements: one 8-byte store into copy 0, two 4-byte stores into the shifted copy
-          union { __bf16 e[4]; uint2 u; unsigned int w[2]; } h, l;
+      if (lds_o[j] >= 0) {
+        const int o = lds_o[j];     // multiple of 4 elements: one 8-byte store into copy 0, two 4-byte stores into copy 1
+        union { __bf16 e[4]; uint2 u; unsigned int w[2]; } h, l;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h.e[e] = (__bf16)hv[j][e];
-            l.e[e] = (__bf16)(hv[j][e] - (float)h.e[e]);
-          }
-          *reinterpret_cast<uint2*>(h_hi + o) = h.u;
-          *reinterpret_cast<unsigned int*>(h_hi + HIMG + o + 2) = h.w[0];
-          *reinterpret_cast<unsigned int*>(h_hi + HIMG + o + 4) = h.w[1];
-          if (NSPLIT == 3) {
-            *reinterpret_cast<uint2*>(h_lo + o) = l.u;
-            *reinterpret_cast<unsigned int*>(h_lo + HIMG + o + 2) = l.w[0];
-            *reinterpret_cast<unsigned int*>(h_lo + HIMG + o + 4) = l.w[1];
-          }
-        } else {
-          const float v = hv[j][0];
-          const __bf16 h = (__bf16)v;
-          h_hi[o] = h;
-          h_hi[HIMG + o + 2] = h;
-          if (NSPLIT == 3) {
-            const __bf16 l = (__bf16)(v - (float)h);
-            h_lo[o] = l;
-            h_lo[HIMG + o + 2] = l;
-          }
+        for (int e = 0; e < 4; ++e) {
+          h.e[e] = (__bf16)hv[j][e];
+          l.e[e] = (__bf16)(hv[j][e] - (float)h.e[e]);
+        }
+        *reinterpret_cast<uint2*>(base + o) = h.u;
+        *reinterpret_cast<unsigned int*>(base + IMG + o + 2) = h.w[0];
+        *reinterpret_cast<unsigned int*>(base + IMG + o + 4) = h.w[1];
+        if (NSPLIT == 3) {
+          *reinterpret_cast<uint2*>(base + 2 * IMG + o) = l.u;
+          *reinterpret_cast<unsigned int*>(base + 3 * IMG + o + 2) = l.w[0];
+          *reinterpret_cast<unsigned int*>(base + 3 * IMG + o + 4) = l.w[1];
         }
       }
+  };
+
+  // this lane's read position inside an image: pixel (patch row prow0 + 2*tile + tyl, column tx), copy by parity of tx
+  const int lanebase = (tx & 1) * (IMG + 2) + 2 * tx + 2 * (prow0 + tyl) * HP;
+  float s1 = 0.f, s2 = 0.f;                     // sum / sum of squares of this lane's channel over its pixels
+
+  for (int f = t0 - 2; f < t0 + 2; ++f) {       // the four frames in front of the first new one
+    fetch(f);
+    stage(f);
+  }
+  fetch(t0 + 2);
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();                            // frame t-3's slot has been read for the last time
+    stage(t + 2);
+    if (t + 1 < t1) fetch(t + 3);               // streams in under this frame's MFMAs
     __syncthreads();
-    if (patch + (int)gridDim.x < npatch) issue(patch + gridDim.x);   // next halo streams in under the MFMAs
-
-    f32x16 acc[2];
+    int slot_o[KT];                             // ring slot (element offset) of temporal tap kt: input frame t + kt - 2
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int kt = 0; kt < KT; ++kt) slot_o[kt] = ((t + kt - 2 + 2 * NRING) % NRING) * SLOT;
+    float* yt = y + (((size_t)b * T + t) * OH) * OW * CO + half * 32 + lr;
+    // byte offset of this lane's row for reduction step s: rows q = 2s (lanes 0-31) and 2s + 1 (lanes 32-63)
+    auto row_off = [&](int s) {
+      const int q0 = 2 * s, q1 = (2 * s + 1 < NQ) ? 2 * s + 1 : 2 * s;   // row 35 is padding: any finite data
+      const int o0 = slot_o[q0 / KH] + (q0 % KH) * HP, o1 = slot_o[q1 / KH] + (q1 % KH) * HP;
+      return 2 * (lh ? o1 : o0);
+    };
+#pragma unroll 1
+    for (int tile = 0; tile < 4; ++tile) {
+      f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-
-#pragma unroll 2
-    for (int ks = 0; ks < KPAD / 16; ++ks) {
-      const int q = ks * 2 + lh;            // (kt, kh) row this lane feeds
-      union { bf16x8 v; uint2 u[2]; } ah, al;
-      ah.u[0] = ah.u[1] = al.u[0] = al.u[1] = make_uint2(0u, 0u);
-      if (q < NQ) {
-        const int kt = q / KH, kh = q - kt * KH;
-        const int o = (tx & 1) * (HIMG + 2) + (kt * HR + 2 * ty + kh) * HC2 + 2 * tx;   // multiple of 4 elements
-        ah.u[0] = *reinterpret_cast<const uint2*>(h_hi + o);
-        ah.u[1] = *reinterpret_cast<const uint2*>(h_hi + o + 4);
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const unsigned tb = ring_addr + 2u * (unsigned)(lanebase + 4 * tile * HP);
+      // The fragment reads are written as single ds_read_b64 instructions: left to the compiler, the two 8-byte halves
+      // of a fragment become one ds_read2_b64, which the LDS serves in four groups of 16 lanes instead of two groups
+      // of 32 (half the rate, and the bank layout above is built for the 32-lane groups).  They are issued AHEAD
+      // steps in front of the MFMAs that consume them.
+      Frag fh[AHEAD + 1], fl[AHEAD + 1];
+#pragma unroll
+      for (int s = 0; s < AHEAD; ++s) lds_read_frag<NSPLIT>(tb + row_off(s), fh[s], fl[s]);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        constexpr int NB = AHEAD + 1;
+        if (s + AHEAD < NSTEP) lds_read_frag<NSPLIT>(tb + row_off(s + AHEAD), fh[(s + AHEAD) % NB], fl[(s + AHEAD) % NB]);
+        // fragments of the steps behind this one that are already requested may stay in flight
+        const int behind = (NSTEP - 1 - s) < AHEAD ? (NSTEP - 1 - s) : AHEAD;
+        if (behind == 0) lds_wait_frag<NSPLIT, 0>(fh[s % NB], fl[s % NB]);
+        else if (behind == 1) lds_wait_frag<NSPLIT, 1>(fh[s % NB], fl[s % NB]);
+        else if (behind == 2) lds_wait_frag<NSPLIT, 2>(fh[s % NB], fl[s % NB]);
+        else lds_wait_frag<NSPLIT, 3>(fh[s % NB], fl[s % NB]);
+        // pixels are the row operand: D[row = pixel][col = channel], so a lane owns one channel, a register quad four
+        // pixels, and every store instruction writes whole 128-byte lines (32 channels of a pixel)
         if (NSPLIT == 3) {
-          al.u[0] = *reinterpret_cast<const uint2*>(h_lo + o);
-          al.u[1] = *reinterpret_cast<const uint2*>(h_lo + o + 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s % NB].v, wl[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s % NB].v, wh[s], acc, 0, 0, 0);
         }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s % NB].v, wh[s], acc, 0, 0, 0);
       }
+      // D[row][col]: col = lane & 31 (channel within the half), row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5) = pixel
+      // of the tile (column row & 15 of patch row prow0 + 2 * tile + (row >> 4))
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int off = (j * 32 + lr) * WROW + ks * 16 + lh * 8;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
-        if (NSPLIT == 3) {
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl, acc[j], 0, 0, 0);
-        }
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh, acc[j], 0, 0, 0);
-      }
-    }
-
-    // D[row][col]: col = lane&31 (channel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (pixel within this wave's 32)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * lh;
-        const int oy = oy0 + wave * 2 + (row >> 4), ox = ox0 + (row & 15);
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int oy = oy0 + prow0 + 2 * tile + (row >> 4), ox = ox0 + (row & 15);
         if (oy < OH && ox < OW) {
-          const float v = acc[j][q];
-          s1[j] += v;
-          s2[j] += v * v;
-          y[((((size_t)b * T + t) * OH + oy) * OW + ox) * CO + j * 32 + lr] = v;
+          const float v = acc[i];
+          s1 += v;
+          s2 += v * v;
+          yt[((size_t)oy * OW + ox) * CO] = v;
         }
       }
     }
   }
   if (stats) {
-    // the workgroup's waves meet in LDS (the weight image is not needed any more): one atomic per statistic and
-    // workgroup instead of one per wave (atomics on one address are resolved one after the other)
-    float* red = reinterpret_cast<float*>(smem);   // [waves][2 * CO]
+    // the two lane halves hold the same channel (different pixels), and so do the two waves of a channel half: they
+    // meet in LDS (the ring is not needed any more); one atomic per statistic and workgroup into a partial buffer
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    float* red = reinterpret_cast<float*>(smem);   // [pixel half][2 * CO]
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float a = s1[j] + __shfl_xor(s1[j], 32, 64), c = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (lh == 0) {
-        red[wave * 2 * CO + j * 32 + lr] = a;
-        red[wave * 2 * CO + CO + j * 32 + lr] = c;
-      }
+    if (lh == 0) {
+      red[(wave >> 1) * 2 * CO + half * 32 + lr] = s1;
+      red[(wave >> 1) * 2 * CO + CO + half * 32 + lr] = s2;
     }
     __syncthreads();
-    if (tid < 2 * CO) {
-      float t = 0.f;
-      for (int k = 0; k < NTHR / 64; ++k) t += red[k * 2 * CO + tid];
-      atomicAdd(stats + tid, t);
-    }
+    if (tid < 2 * CO) atomicAdd(stats + (size_t)(unit % stat_slots) * 2 * CO + tid, red[tid] + red[2 * CO + tid]);
   }
 }
 
 }  // namespace
 
+extern "C" long long vca_stem_pack_bytes() { return (long long)WFRAG_U4 * 16; }
+
 extern "C" int vca_stem_pack_weight(const float* w, void* wpack, void* stream) {
   VCA_CHECK_ARG(w && wpack);
-  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((CO * WROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((2 * NSTEP * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
                      reinterpret_cast<__bf16*>(wpack));
   return vca_launch_status();
 }
 
 extern "C" int vca_stem_fwd_bf16(int nsplit, int B, int T, int H, int W, const float* x, const void* wpack, float* y,
-                                 float* stats, void* stream) {
+                                 float* stats, int stat_slots, void* stream) {
   VCA_CHECK_ARG((nsplit == 1 || nsplit == 3) && B > 0 && T > 0 && H > 0 && W > 0 && x && wpack && y);
+  VCA_CHECK_ARG(stats == nullptr || stat_slots >= 1);
+  VCA_CHECK_ARG((reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   const int tiles_y = (OH + PH - 1) / PH, tiles_x = (OW + PW - 1) / PW;
-  const long long npatch = (long long)B * T * tiles_y * tiles_x;
-  VCA_CHECK_ARG(npatch < (1ll << 31));
-  const size_t lds = (size_t)(nsplit == 3 ? 2 : 1) * CO * WROW * 2 + (size_t)4 * HIMG * 2 + 16;
+  const int tchunks = (T + TCHUNK - 1) / TCHUNK;
+  const long long nunits = (long long)B * tiles_y * tiles_x * tchunks;
+  VCA_CHECK_ARG(nunits < (1ll << 28) && (long long)H * W < (1ll << 31) - 8);
+  const size_t lds = (size_t)NRING * (nsplit == 3 ? 4 : 2) * IMG * 2;
   VCA_MAX_LDS((stem_fwd_kernel<3, true>));
   VCA_MAX_LDS((stem_fwd_kernel<1, true>));
   VCA_MAX_LDS((stem_fwd_kernel<3, false>));
   VCA_MAX_LDS((stem_fwd_kernel<1, false>));
-  int grid = 256;   // one 8-wave workgroup per CU (LDS: weights 37/74 KiB + halo images 64 KiB)
-  if (grid > npatch) grid = (int)npatch;
-  const __bf16* wp = reinterpret_cast<const __bf16*>(wpack);
+  const int grid = (int)((nunits + 7) / 8) * 8;
+  const uint4* wp = reinterpret_cast<const uint4*>(wpack);
   const bool vec = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 #define LAUNCH_STEM(NS, V)                                                                                          \
   hipLaunchKernelGGL((stem_fwd_kernel<NS, V>), dim3(grid), dim3(NTHR), lds, (hipStream_t)stream, B, T, H, W, OH, OW, \
-                     x, wp, y, stats, tiles_y, tiles_x, (int)npatch)
+                     x, wp, y, stats, stat_slots, tiles_y, tiles_x, tchunks, (int)nunits)
   if (nsplit == 3) {
     if (vec) LAUNCH_STEM(3, true); else LAUNCH_STEM(3, false);
   } else {

@@ -731,7 +731,7 @@ class StemConvFn(torch.autograd.Function):
                 wp = ent[1][key][1]
         if wp is None:
             old = ent[1][key][1] if (cacheable and ent is not None and ent[0]() is w and key in ent[1]) else None
-            wp = old if old is not None else torch.empty(2 * 64 * 296 * 2, device=x.device, dtype=torch.uint8)
+            wp = old if old is not None else torch.empty(L.vca_stem_pack_bytes(), device=x.device, dtype=torch.uint8)
             check(L.vca_stem_pack_weight(ptr(_c(w.detach())), wp.data_ptr(), stream()), 'stem_pack')
             if cacheable:
                 k2 = id(w)
@@ -741,9 +741,9 @@ class StemConvFn(torch.autograd.Function):
                     _pack_cache[k2] = ent
                 ent[1][key] = (_wkey(w), wp)
         y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
-        stats = _zeros((2, 64), x.device)
-        check(L.vca_stem_fwd_bf16(_nsplit(), B, T, H, W, ptr(x), wp.data_ptr(), ptr(y), ptr(stats), stream()),
-              'stem_fwd')
+        stats = _zeros((CONV_STAT_SLOTS, 2, 64), x.device)     # partial buffers, totalled by the batch-norm finalize
+        check(L.vca_stem_fwd_bf16(_nsplit(), B, T, H, W, ptr(x), wp.data_ptr(), ptr(y), ptr(stats), CONV_STAT_SLOTS,
+                                  stream()), 'stem_fwd')
         ctx.save_for_backward(x, w)
         ctx.cfg = cfg
         ctx.mark_non_differentiable(stats)
