@@ -151,6 +151,57 @@ def cpu_baseline():
                 sample='%d full G+D steps at B2xT75x112x112 fp32 (oracle/cpu_ref.py), %.2f s/step' % (n, dt))
 
 
+def bench_buckets(args, step, device, train_step, result_fd):
+    """train_LRS.py steps over a synthetic dataset of ragged clip lengths, batches drawn per length bucket
+    (train_step.bucket_batches) and replayed from one captured step per bucket (train_step.BucketedStep).  Reports
+    frames/s over VALID frames beside the padded figure, and what padding every clip to 150 frames would give."""
+    g = torch.Generator().manual_seed(11)
+    nb = max(args.steps, 10)
+    lengths = [int(v) for v in torch.randint(40, 151, (args.batch * nb * 2,), generator=g)]
+    batches = train_step.bucket_batches(lengths, args.batch, seed=5)[:nb]
+    data = {}
+    for Tb in sorted({Tb for Tb, _ in batches} | {150}):
+        data[Tb] = synth(args.batch, Tb, H, device, 1234 + Tb)
+    run = train_step.BucketedStep(step)
+
+    def one(Tb, idx):
+        d = data[Tb]
+        return run(d['mel'], d['spec'], d['vid'], [lengths[i] for i in idx])
+    for Tb in sorted(data):                       # first batch of a bucket: eager step + capture
+        one(Tb, list(range(args.batch)))
+    for Tb, idx in batches[:args.warmup]:
+        one(Tb, idx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        Tb, idx = batches[k % len(batches)]
+        out = one(Tb, idx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    used = [batches[k % len(batches)] for k in range(args.steps)]
+    valid = sum(lengths[i] for _, idx in used for i in idx)
+    padded = sum(Tb * len(idx) for Tb, idx in used)
+    per_bucket = {}
+    for Tb in sorted(data):
+        per_bucket[str(Tb)] = round(_time(lambda: one(Tb, list(range(args.batch))), reps=3, warm=1) * 1e3, 2)
+    ms150 = per_bucket['150']
+    assert torch.isfinite(out['gen_loss']).item() and torch.isfinite(out['dis_loss']).item()
+    res = {'metric': 'lip-video VALID frames/sec (train_LRS.py G+D step, length buckets) @ B%d x 96x96 per GPU' % args.batch,
+           'value': round(valid / dt, 1), 'unit': 'frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+           'config': {'workload': 'train_LRS.py full GAN step on clips of 40-150 valid frames, batches of %d drawn per '
+                                  'length bucket %r and padded to the bucket, one captured step per bucket in a shared '
+                                  'memory pool' % (args.batch, list(train_step.LRS_BUCKETS))},
+           'padded_frames_per_s': round(padded / dt, 1),
+           'valid_fraction_of_padded': round(valid / padded, 3),
+           'ms_per_step_by_bucket': per_bucket,
+           'pad_every_clip_to_150': {'ms_per_step': ms150, 'valid_frames_per_s': round(valid / args.steps / (ms150 * 1e-3), 1)},
+           'batches_per_bucket': {str(Tb): sum(1 for t, _ in used if t == Tb) for Tb in sorted(data)}}
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(res) + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -164,10 +215,12 @@ def main():
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand every step its inputs as pinned host tensors (copied to the device on the compute stream '
                          'before the replay, not overlapped): the PCIe-inclusive rate, an extra measurement')
-    ap.add_argument('--workload', default='grid', choices=['grid', 'lrs', 'lrs_ctc'],
+    ap.add_argument('--workload', default='grid', choices=['grid', 'lrs', 'lrs_ctc', 'lrs_buckets'],
                     help="grid: BASELINE configs[1] (the headline).  lrs: the train_LRS.py step at configs[3]'s shape "
                          '(batch 16/GPU, clips padded to T=150, ragged valid lengths).  lrs_ctc: the same with the CTC '
-                         'auxiliary loss of the frozen ASR scorer (configs[4]).  Extra measurements, never the headline.')
+                         'auxiliary loss of the frozen ASR scorer (configs[4]).  lrs_buckets: the lrs step on clips of '
+                         'ragged lengths grouped into length buckets (50/75/100/125/150 frames), one captured step per '
+                         'bucket.  Extra measurements, never the headline.')
     args = ap.parse_args()
     global T
     lrs = args.workload != 'grid'
@@ -231,6 +284,8 @@ def main():
         from vcagan_amd.models import asr
         ctc = dict(front=asr.Audio_front().to(device), back=asr.Backend().to(device), weight=1.0)
     step = train_step.GanStep(models, opts, 'lrs' if lrs else 'grid', ctc=ctc)
+    if args.workload == 'lrs_buckets':
+        return bench_buckets(args, step, device, train_step, result_fd)
     data = synth(args.batch, T, H, device, 1234 + rank)
     text = text_len = None
     if lrs:

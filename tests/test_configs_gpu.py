@@ -126,6 +126,66 @@ def test_lrs_step_long_ragged(prec, atol, lrt, grel):
     _check_step(ref, hip, want, got, lrt, atol, grel)
 
 
+def test_bucket_batches_group_by_padded_length():
+    """Host-side batch sampler of the length buckets (no GPU): every batch comes from one bucket, every index is used
+    at most once, clips are padded to the smallest bucket that holds them."""
+    from vcagan_amd import train_step as ts
+    lens = [50, 51, 75, 76, 149, 150, 33, 100, 101, 125, 60, 70]
+    assert [ts.bucket_of(n) for n in (1, 50, 51, 150)] == [50, 50, 75, 150]
+    with pytest.raises(ValueError):
+        ts.bucket_of(151)
+    bb = ts.bucket_batches(lens, 2, seed=3)
+    seen = [i for _, idx in bb for i in idx]
+    assert len(seen) == len(set(seen))
+    for T, idx in bb:
+        assert len(idx) == 2 and all(ts.bucket_of(lens[i]) == T for i in idx)
+    full = ts.bucket_batches(lens, 2, seed=3, drop_last=False)
+    assert sorted(i for _, idx in full for i in idx) == list(range(len(lens)))
+
+
+@gpu
+def test_length_buckets_replay_matches_eager():
+    """train_LRS.py steps on clips padded to two different bucket lengths, alternating (BASELINE configs[3]
+    'bucketing'): BucketedStep (one captured step per bucket in a shared memory pool, first batch of a bucket eager)
+    against the same sequence issued kernel by kernel.  Both runs draw the same device-side noise and dropout masks
+    (same seed, same step counter)."""
+    from vcagan_amd import ops, train_step as ts
+    ops.set_precision('mixed')
+    B, H = 2, 96
+    seq = [50, 75, 50, 75, 75, 50]
+    batches = {T: _dev(fixtures.make_batch(B, T, H, 60 + T, [T, T - 11])) for T in (50, 75)}
+    out = {}
+    for mode in ('eager', 'bucketed'):
+        m = fixtures.fill_models(ts.build_models(), 900)
+        for k in m:
+            m[k].cuda().train()
+        step = ts.GanStep(m, ts.build_optimizers(m, amsgrad=False), 'lrs')
+        ops.set_seed(77)
+        if torch.device('cuda', 0) in ops._rng_step:
+            ops._rng_step[torch.device('cuda', 0)].zero_()
+        run = ts.BucketedStep(step) if mode == 'bucketed' else \
+            (lambda mel, spec, vid, vl: step(mel, spec, vid, vl, noise='device'))
+        res = []
+        for T in seq:
+            b = batches[T]
+            r = run(b['mel'], b['spec'], b['vid'], b['vid_len'])
+            res.append({k: float(r[k]) for k in LOSSES} | {'g3': tuple(r['g3'].shape)})
+        torch.cuda.synchronize()
+        out[mode] = res
+        if mode == 'bucketed':
+            assert sorted(run.graphed) == [50, 75] and all(len(g.graphs) == 1 for g in run.graphed.values())
+        del m, step, run
+        torch.cuda.empty_cache()
+    for i, (a, b) in enumerate(zip(out['eager'], out['bucketed'])):
+        assert a['g3'] == b['g3'] == (B, 1, 80, 4 * seq[i])
+        # Step 0 is the same eager launch sequence in both runs.  fp32 atomics make two runs differ in the last bits and
+        # every sign-like Adam update amplifies that (same bounds as the other replay tests): step 1 (eager in both,
+        # behind one update), then replays against eager launches.
+        tol = (2e-5, 3e-3)[i] if i < 2 else 3e-2
+        for k in LOSSES:
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+
+
 @gpu
 def test_full_size_step_eager_vs_replay():
     """The benchmark's own shape and precision, B32 x T75 x 96x96 in 'mixed' (BASELINE configs[1]): every loss is

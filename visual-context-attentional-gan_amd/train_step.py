@@ -334,7 +334,9 @@ class GraphedStep:
     supplies the noise of every call (passing None on a later call is an error, never a silent reuse)."""
 
     def __init__(self, step, mel, spec, vid, vid_len, noise='device', warmup=2, segmented=None, text=None,
-                 text_len=None):
+                 text_len=None, pool=None):
+        """pool: a torch.cuda.graph_pool_handle() shared with other GraphedSteps whose replays never overlap (the
+        length buckets of BucketedStep): their captures then reuse one another's activation memory."""
         assert warmup >= 1, 'one uncaptured step must run first: lazy state and the scratch arena settle there'
         if D_STREAMS and G.HEAD_STREAMS:
             # fork + join on a forked stream: hipStreamEndCapture of this runtime crashes the process (see
@@ -357,19 +359,19 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):          # allocator, lazy module state and kernel attributes settle here
-                self._run()
+                self.warm_out = self._run()  # (real training steps on the given batch; the last one's results)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         s = self.static
         nz = 'device' if self.device_noise else s['noise']
         if not self.segmented:
             self.graphs = [torch.cuda.CUDAGraph()]
-            with torch.cuda.graph(self.graphs[0]):
+            with torch.cuda.graph(self.graphs[0], pool=pool):
                 self.out = self._run()
         else:
             # Other threads (the process group's watchdog) may touch the device while a phase is being captured.
             mode = 'thread_local' if step.d_exchange.active else 'global'
-            pool = torch.cuda.graph_pool_handle()
+            pool = torch.cuda.graph_pool_handle() if pool is None else pool
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
                 step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz, s['text'], s['text_len'])
@@ -412,3 +414,67 @@ class GraphedStep:
             self.step.g_exchange.reduce()
             self.graphs[2].replay()
         return self.out
+
+
+LRS_BUCKETS = (50, 75, 100, 125, 150)
+
+
+def bucket_of(n_frames, buckets=LRS_BUCKETS):
+    """The padded clip length a clip of n_frames is trained at: the smallest bucket that holds it."""
+    for b in buckets:
+        if n_frames <= b:
+            return b
+    raise ValueError('a clip of %d frames exceeds the largest bucket (%d)' % (n_frames, buckets[-1]))
+
+
+def bucket_batches(lengths, batch_size, buckets=LRS_BUCKETS, seed=None, drop_last=True):
+    """Batch sampler for variable-length clips (the train_LRS.py loop pads every clip to one window,
+    vid_aud_lrs2.py:106,171-188, so a 60-frame clip costs as much as a 150-frame one): sample indices are grouped by
+    bucket_of(length) and each batch is drawn from one bucket, so it is padded to that bucket's length only.
+    Returns [(T_bucket, [indices]), ...] in a (seeded) shuffled order, like DataLoader(shuffle=True) over batches."""
+    import random
+    rng = random.Random(seed)
+    by = {}
+    for i, n in enumerate(lengths):
+        by.setdefault(bucket_of(int(n), buckets), []).append(i)
+    out = []
+    for T, idx in sorted(by.items()):
+        if seed is not None:
+            rng.shuffle(idx)
+        for k in range(0, len(idx), batch_size):
+            chunk = idx[k:k + batch_size]
+            if len(chunk) == batch_size or not drop_last:
+                out.append((T, chunk))
+    if seed is not None:
+        rng.shuffle(out)
+    return out
+
+
+class BucketedStep:
+    """A GanStep for clips of several padded lengths: one captured step (GraphedStep) per bucket length, captured the
+    first time a batch of that length arrives, all captures in one memory pool (replays are sequential, so the
+    buckets reuse each other's activation memory).  The batch size is fixed; a batch's length is vid.shape[2] and must
+    be one of `buckets` (bucket_batches groups a dataset that way; the valid lengths inside the batch still go through
+    vid_len and reach the attention masks, generator.py:162-163).
+
+    The first batch of a bucket is trained eagerly (it is the warm-up step every capture needs) and the capture
+    follows; from its second batch on a bucket costs one graph replay."""
+
+    def __init__(self, step, buckets=LRS_BUCKETS, noise='device'):
+        assert isinstance(noise, str), 'bucketed steps draw the decoder noise on the device'
+        self.step, self.buckets = step, tuple(buckets)
+        self.pool = None
+        self.graphed = {}
+
+    def __call__(self, mel, spec, vid, vid_len, text=None, text_len=None):
+        T = int(vid.shape[2])
+        assert T in self.buckets, 'clip length %d is not one of the buckets %r' % (T, self.buckets)
+        assert mel.shape[-1] == 4 * T and spec.shape[-1] == 4 * T
+        gs = self.graphed.get(T)
+        if gs is None:
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            gs = self.graphed[T] = GraphedStep(self.step, mel, spec, vid, vid_len, 'device', warmup=1, text=text,
+                                               text_len=text_len, pool=self.pool)
+            return gs.warm_out
+        return gs(mel, spec, vid, vid_len, text=text, text_len=text_len)
