@@ -212,9 +212,10 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra mixed-precision measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
     ap.add_argument('--precision', default='mixed', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
-    ap.add_argument('--host-inputs', action='store_true',
-                    help='hand every step its inputs as pinned host tensors (copied to the device on the compute stream '
-                         'before the replay, not overlapped): the PCIe-inclusive rate, an extra measurement')
+    ap.add_argument('--host-inputs', nargs='?', const='inline', default=None, choices=['inline', 'prefetch'],
+                    help='hand every step its inputs as pinned host tensors: the PCIe-inclusive rate, an extra '
+                         'measurement.  inline: copied on the compute stream in front of the replay, nothing overlapped; '
+                         'prefetch: copied one batch ahead on a side stream (video.InputPrefetcher)')
     ap.add_argument('--workload', default='grid', choices=['grid', 'lrs', 'lrs_ctc', 'lrs_buckets'],
                     help="grid: BASELINE configs[1] (the headline).  lrs: the train_LRS.py step at configs[3]'s shape "
                          '(batch 16/GPU, clips padded to T=150, ragged valid lengths).  lrs_ctc: the same with the CTC '
@@ -309,15 +310,24 @@ def main():
             sys.exit(3)
 
     feed = data
+    prefetch = None
     if args.host_inputs and graphed is not None:
         feed = {k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in data.items()}
+        if args.host_inputs == 'prefetch':
+            from vcagan_amd import video
+            import itertools
+            host = {k: feed[k] for k in ('mel', 'spec', 'vid')}
+            prefetch = video.InputPrefetcher(itertools.repeat(host), device)
 
     trace_loss = os.environ.get('VCA_BENCH_TRACE_LOSS')    # debugging aid: '1' prints the losses, 'sync' only syncs
 
     def run(n):
         out = None
         for _ in range(n):
-            if graphed is not None:
+            if prefetch is not None:
+                dev_in = next(prefetch)          # already on the device: copied under the previous step
+                out = graphed(dev_in['mel'], dev_in['spec'], dev_in['vid'])
+            elif graphed is not None:
                 out = graphed(feed['mel'], feed['spec'], feed['vid'])
             else:
                 out = step(data['mel'], data['spec'], data['vid'], data['vid_len'], noise='device', text=text,
@@ -376,7 +386,8 @@ def main():
                        'parallelism': 'dp%d' % world,
                        'noise': 'decoder noise drawn afresh inside every timed step, on the device (counter-based '
                                 'generator) instead of torch.randn on the CPU + host-to-device copy'},
-            'inputs': 'pinned host tensors, copied in every step' if feed is not data else 'resident in HBM',
+            'inputs': ('pinned host tensors, copied one batch ahead on a side stream' if prefetch is not None else
+                       'pinned host tensors, copied in every step') if feed is not data else 'resident in HBM',
             'ref_algorithmic_tflops': round(FLOP_PER_FRAME * frames / (ms * 1e-3) / 1e12, 2),
             'final_losses': {'gen': round(float(out['gen_loss']), 4), 'dis': round(float(out['dis_loss']), 4)},
         }

@@ -66,3 +66,55 @@ def test_prefetcher_matches_synchronous_path():
     assert lens == [9, 7, 6] and meta['start'] is None
     assert torch.equal(out, vt(torch.from_numpy(batches[0][0]).to(dev), lens, Tin))
     assert float(out[1, :, 7:].abs().max()) == 0.0
+
+
+@gpu
+def test_prefetcher_carries_the_window_of_the_audio_targets():
+    """A source that also yields the mel / spectrogram targets (4 frames per video frame, vid_aud_grid.py:160): the
+    prefetcher cuts them with each clip's drawn window (extract_window, vid_aud_grid.py:172-188), stages them through
+    pinned buffers and copies them on its side stream; every batch arrives with the slices the host would have cut,
+    while the consumer keeps its stream busy and reads the tensors late."""
+    import random
+    from vcagan_amd import video
+    dev = torch.device('cuda', 0)
+    vt = video.VideoTransform(dev)
+    B, Tin, W = 2, 9, 5
+    g = torch.Generator().manual_seed(4)
+    batches = []
+    for i in range(6):
+        mel = torch.randn(B, 1, 80, 4 * Tin, generator=g)
+        spec = torch.rand(B, 1, 321, 4 * Tin, generator=g)
+        batches.append((_frames(B, Tin, seed=30 + i), [9, 8], dict(mel=(mel, 4), spec=(spec, 4))))
+    random.seed(5)
+    pf = video.VideoPrefetcher(iter(batches), vt, max_t=W, window=W, augment=False, depth=2)
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for out, lens, meta in pf:
+        busy = busy @ busy * 1e-3
+        mel_d, spec_d = meta['extra']['mel'], meta['extra']['spec']
+        assert mel_d.is_cuda and mel_d.shape == (B, 1, 80, 4 * W) and spec_d.shape == (B, 1, 321, 4 * W)
+        got.append((meta['start'], (mel_d * 1.0), (spec_d * 1.0)))     # read on the consumer's stream, behind `busy`
+    assert len(got) == len(batches)
+    for (fr, n, ex), (start, mel_d, spec_d) in zip(batches, got):
+        for b in range(B):
+            assert torch.equal(mel_d[b].cpu(), ex['mel'][0][b, ..., 4 * start[b]:4 * (start[b] + W)])
+            assert torch.equal(spec_d[b].cpu(), ex['spec'][0][b, ..., 4 * start[b]:4 * (start[b] + W)])
+
+
+@gpu
+def test_input_prefetcher_hands_out_each_batch_once_and_intact():
+    """InputPrefetcher (host-to-device copies one batch ahead on a side stream, two alternating device buffer sets):
+    every batch arrives intact and in order although the consumer's stream is kept busy and reads its tensors late."""
+    from vcagan_amd import video
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(9)
+    host = [dict(vid=torch.randn(2, 1, 6, 32, 32, generator=g).pin_memory(),
+                 mel=torch.randn(2, 1, 80, 24, generator=g).pin_memory(), vid_len=[6, 5 - (i % 2)]) for i in range(7)]
+    busy = torch.randn(2048, 2048, device=dev)
+    seen = []
+    for batch in video.InputPrefetcher(iter(host), dev):
+        busy = busy @ busy * 1e-3
+        seen.append((batch['vid'] + 0.0, batch['mel'] + 0.0, batch['vid_len']))
+    assert len(seen) == len(host)
+    for h, (v, m, n) in zip(host, seen):
+        assert torch.equal(v.cpu(), h['vid']) and torch.equal(m.cpu(), h['mel']) and n == h['vid_len']

@@ -104,8 +104,12 @@ class VideoPrefetcher:
     `vid.cuda()` in the reference loop (train.py:139-146,173), with extract_window's sampling (vid_aud_grid.py:172-188)
     done on the device through the transform kernel's per-clip start offsets.
 
-    `source` yields (frames, n_frames): decoded RGB clips as one uint8 array (B, Tin, H0, W0, 3) on the host and the
-    number of valid frames of each clip.  Per batch the host draws the window starts and the augmentations, copies
+    `source` yields (frames, n_frames) or (frames, n_frames, extras): decoded RGB clips as one uint8 array
+    (B, Tin, H0, W0, 3) on the host, the number of valid frames of each clip, and optionally a dict of further host
+    tensors name -> (tensor (B, ..., ratio * Tin), ratio) whose last axis is time at `ratio` steps per video frame (the
+    mel and spectrogram targets, ratio 4: vid_aud_grid.py:160,172-188 cuts them with the clip's window).  They are
+    cut to the drawn window on the host, staged through pinned buffers of their own and copied on the same side
+    stream, so a training step finds all of its inputs on the device; they come back as meta['extra'][name].  Per batch the host draws the window starts and the augmentations, copies
     the frames into one of `depth` pinned staging buffers, and on a side stream issues the host-to-device copy and the
     transform kernel; iteration hands out the finished (B, 1, T, 112, 112) tensor after making the consumer's stream
     wait for that work, and immediately stages the next batch, so copy and transform overlap the step that is
@@ -117,7 +121,7 @@ class VideoPrefetcher:
         self.src = iter(source)
         self.vt, self.max_t, self.window, self.augment = transform, max_t, window, augment
         self.side = torch.cuda.Stream(device=transform.device)
-        self.slots = [dict(pinned=None, dev=None, copied=None) for _ in range(depth)]
+        self.slots = [dict(pinned=None, dev=None, copied=None, extra={}) for _ in range(depth)]
         self.queue = []          # staged batches in order: (tensor, lens, meta, ready event)
         self.k = 0
         self.done = False
@@ -128,10 +132,12 @@ class VideoPrefetcher:
         if self.done:
             return
         try:
-            frames, n_frames = next(self.src)
+            item = next(self.src)
         except StopIteration:
             self.done = True
             return
+        frames, n_frames = item[0], item[1]
+        extras = item[2] if len(item) > 2 else {}
         frames = torch.as_tensor(frames)
         assert frames.dtype == torch.uint8 and frames.dim() == 5
         B = frames.shape[0]
@@ -149,16 +155,35 @@ class VideoPrefetcher:
             slot['pinned'] = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
             slot['dev'] = torch.empty(frames.shape, dtype=torch.uint8, device=self.vt.device)
         slot['pinned'].copy_(frames)
+        ex_host = {}
+        for name, (t, ratio) in extras.items():
+            t = torch.as_tensor(t)
+            if start is not None:       # the clip's window on this tensor's time axis
+                t = torch.stack([t[b, ..., ratio * start[b]:ratio * (start[b] + self.window)] for b in range(B)])
+            buf = slot['extra'].get(name)
+            if buf is None or buf[0].shape != t.shape or buf[0].dtype != t.dtype:
+                buf = slot['extra'][name] = (torch.empty(t.shape, dtype=t.dtype, pin_memory=True),
+                                             torch.empty(t.shape, dtype=t.dtype, device=self.vt.device))
+            buf[0].copy_(t)
+            ex_host[name] = buf
         # the device staging buffer is only ever touched on the side stream, so stream order protects its reuse and
         # nothing here waits for the consumer's stream (that wait would serialise the copy behind the running step)
         with torch.cuda.stream(self.side):
             slot['dev'].copy_(slot['pinned'], non_blocking=True)
+            extra = {}
+            if ex_host and getattr(self, 'release', None) is not None:
+                self.side.wait_event(self.release)
+            for name, (pin, dev) in ex_host.items():
+                dev.copy_(pin, non_blocking=True)
+                extra[name] = dev
             slot['copied'] = torch.cuda.Event()
             slot['copied'].record(self.side)
             out = self.vt(slot['dev'], lens, self.max_t, flip, erase, start)
             ready = torch.cuda.Event()
             ready.record(self.side)
-        self.queue.append((out, lens, dict(flip=flip, erase=erase, start=start), ready))
+        # (an extra's device buffer belongs to its slot: it is overwritten `depth` batches later, behind the
+        # consumer's wait below, so a consumer that keeps it longer than that clones it)
+        self.queue.append((out, lens, dict(flip=flip, erase=erase, start=start, extra=extra), ready))
 
     def __iter__(self):
         return self
@@ -172,5 +197,66 @@ class VideoPrefetcher:
         cur = torch.cuda.current_stream(self.vt.device)
         cur.wait_event(ready)
         out.record_stream(cur)
+        # Everything the consumer has enqueued so far belongs to earlier batches.  The staging below reuses the slot of
+        # the batch handed out before this one, whose extras live in the slot's own device buffers: the side stream
+        # waits for this point of the consumer's stream before it overwrites them.
+        self.release = torch.cuda.Event()
+        self.release.record(cur)
         self._stage()                                # the next batch's copy + transform overlap the caller's step
         return out, lens, meta
+
+
+class InputPrefetcher:
+    """Host-to-device copies of a training step's inputs one batch ahead, on a side stream: the pin_memory + .cuda()
+    hand-over of the reference loop (train.py:139-146,173,182-186) without the copy sitting in front of the step.
+    `batches` yields dicts of pinned host tensors (equal shapes from batch to batch).  Iteration returns a dict of
+    device tensors valid until the next call of next(); two device buffer sets alternate: while the consumer's step
+    reads one, the side stream fills the other, and the side stream waits for the consumer's stream before it
+    overwrites a set (an event recorded at the following next())."""
+
+    def __init__(self, batches, device):
+        self.src = iter(batches)
+        self.device = device
+        self.side = torch.cuda.Stream(device=device)
+        self.sets = [None, None]
+        self.free = [None, None]       # event after which set i may be overwritten
+        self.k = 0
+        self.staged = None
+        self._stage()
+
+    def _stage(self):
+        try:
+            host = next(self.src)
+        except StopIteration:
+            self.staged = None
+            return
+        i = self.k % 2
+        self.k += 1
+        if self.sets[i] is None:
+            self.sets[i] = {n: torch.empty(t.shape, dtype=t.dtype, device=self.device) for n, t in host.items()
+                            if torch.is_tensor(t)}
+        with torch.cuda.stream(self.side):
+            if self.free[i] is not None:
+                self.side.wait_event(self.free[i])
+            for n, t in host.items():
+                if torch.is_tensor(t):
+                    self.sets[i][n].copy_(t, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        self.staged = (i, dict(self.sets[i], **{n: t for n, t in host.items() if not torch.is_tensor(t)}), ready)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.staged is None:
+            raise StopIteration
+        i, out, ready = self.staged
+        cur = torch.cuda.current_stream(self.device)
+        # whatever the consumer enqueued so far (its reads of the OTHER set) is what the next copy into that set waits for
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.free[1 - i] = ev
+        cur.wait_event(ready)
+        self._stage()
+        return out
