@@ -150,6 +150,27 @@ typedef struct vca_pack_desc {
 } vca_pack_desc;
 int vca_pack_weight_bf16_batch(const vca_pack_desc* table, int ndesc, int total_tiles, int max_taps, void* stream);
 
+/* Linear layers and 1x1 / stride-1 convolutions in split-bf16 (nn.Linear: generator.py:145-148,299,302,335,
+ * visual_front.py:21, the input products of nn.GRU visual_front.py:20; pointwise nn.Conv2d / nn.Conv1d:
+ * generator.py:25,68,108,184,212-224), forward and - with the input-gradient weight pack - input gradient:
+ *   C[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]) (+ res[m][n]),   m < M, n < N, k < K (K a multiple of 8).
+ * wpack: vca_pack_weight_bf16 mode 0 of the (N, K) weight for the forward pass, mode 1 of the (K, N) weight for the
+ * input gradient (taps = 1).  A and C (and res, laid out like C) may be strided views, which is how the attention
+ * projections read and write channels-last maps without the view / permute copies of generator.py:159,169:
+ *   A[m][k] at a + (m / a_tm) * a_bs + (m % a_tm) * a_ts + (k / a_ck) * a_ks + (k % a_ck)
+ *   C[m][n] at c + (m / c_tm) * c_bs + (m % c_tm) * c_ts + (n / c_cn) * c_ns + (n % c_cn)        (in floats)
+ * with a_ck a multiple of 32 (or >= K), every A stride a multiple of 4 and a 16-byte aligned; a plain row-major
+ * matrix is a_tm = M, a_ts = row stride, a_ck = K.  Descriptors that do not meet this return -22. */
+typedef struct vca_lin_desc {
+  int M, N, K;
+  int a_tm, a_ck;
+  long long a_bs, a_ts, a_ks;
+  int c_tm, c_cn;
+  long long c_bs, c_ts, c_ns;
+} vca_lin_desc;
+int vca_linear_bf16(const vca_lin_desc* d, int nsplit, const float* a, const void* wpack, const float* bias,
+                    const float* res, float* c, void* stream);
+
 /* Conv3d stem of the visual front-end (nn.Conv3d(1, 64, (5,7,7), (1,2,2), (2,3,3), bias=False),
  * visual_front.py:11) in split-bf16: x is the single-channel video [B][T][H][W], y the channels-last feature map
  * [B][T][OH][OW][64] with OH = (H-1)/2+1.  wpack (vca_stem_pack_bytes() bytes, 16-byte aligned: the hi/lo bf16

@@ -54,13 +54,27 @@ for (kind, xs, ws, stride, ph, pw, ups), cnt in seen.items():
           'wgrad': lambda: ops._conv_wgrad_raw(x, gy, cfg)}[kind]
     fn(); fn()
     torch.cuda.synchronize()
+    # ten launches captured into a graph and replayed: device time per launch without the host's launch overhead
+    # (issued from Python, anything shorter than ~25 us measures the interpreter, not the kernel)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(10):
+            fn()
+    gr.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
-        fn()
+        gr.replay()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 3
+    ms = e0.elapsed_time(e1) / 30
+    del gr
     taps = cfg.kd * cfg.kh * cfg.kw
     P = 1
     for s in cfg.yshape[:-1]:
@@ -70,5 +84,5 @@ for (kind, xs, ws, stride, ph, pw, ups), cnt in seen.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total conv ms/step %.1f' % tot)
-for r in rows[:60]:
+for r in rows[:int(os.environ.get("CONV_BENCH_ROWS", "60"))]:
     print('%7.2fms %-5s x=%-22s w=%-20s s%d u%d n=%2d %7.3fms %8.1fGF %7.1f TF/s' % r)

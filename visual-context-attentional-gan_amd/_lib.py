@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
-           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip', 'wgrad_cin1.hip')
+           'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip', 'wgrad_cin1.hip', 'linear.hip')
 
 
 def build(force=False, verbose=False):
@@ -36,6 +36,13 @@ class ConvDesc(ctypes.Structure):
                 ('N', 'D', 'Hin', 'Win', 'Cin', 'OD', 'OH', 'OW', 'Cout', 'KD', 'KH', 'KW', 'stride', 'pad_h',
                  'pad_w', 'pad_d', 'dil', 'ups', 'act')] + [('slope', ctypes.c_float), ('out_scale', ctypes.c_float),
                                                                ('d2s_h', ctypes.c_int), ('d2s_w', ctypes.c_int)]
+
+
+class LinDesc(ctypes.Structure):
+    _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int), ('a_tm', ctypes.c_int),
+                ('a_ck', ctypes.c_int), ('a_bs', ctypes.c_longlong), ('a_ts', ctypes.c_longlong),
+                ('a_ks', ctypes.c_longlong), ('c_tm', ctypes.c_int), ('c_cn', ctypes.c_int),
+                ('c_bs', ctypes.c_longlong), ('c_ts', ctypes.c_longlong), ('c_ns', ctypes.c_longlong)]
 
 
 class LossHead(ctypes.Structure):
@@ -71,6 +78,7 @@ _SIGS = {
     'vca_pack_weight_bf16_bytes': ([_I, _I, _I, _I], _LL),
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_pack_weight_bf16_batch': ([_P, _I, _I, _I, _P], _I),
+    'vca_linear_bf16': ([ctypes.POINTER(LinDesc), _I, _P, _P, _P, _P, _P, _P], _I),
     'vca_stem_pack_weight': ([_P, _P, _P], _I),
     'vca_stem_pack_bytes': ([], _LL),
     'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], _I),

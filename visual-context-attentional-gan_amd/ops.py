@@ -272,11 +272,43 @@ def _split_ws(cfg, role, d, device):
     return torch.empty(n, device=device, dtype=torch.float32), n
 
 
+LINEAR_KERNEL = __import__('os').environ.get('VCA_LINEAR', '1') != '0'    # False: pointwise convolutions / linear layers on the general convolution kernel (A/B switch)
+
+
+# The linear kernel streams both operands from L2 without an LDS stage: no fixed cost, but three times the L2 bytes
+# per MFMA of the convolution kernel's 128 x 128 tiles.  Device time per launch (graph replay, tools/conv_bench.py):
+# 20-40 % shorter up to ~1 GFLOP (discriminator heads and shortcuts, 512 -> 256 projections: 10-19 us against 17-27),
+# level at 2-4 GFLOP, up to 2x longer beyond (2400 x 5120 -> 512: 177 against 98 us).
+LINEAR_MAX_FLOP = 1.5e9
+
+
+def _pointwise(cfg, k, rows=None, n=None):
+    """True for a 1x1 / stride-1 / unpadded convolution (a linear layer over the rows of a channels-last matrix) that
+    goes to the linear kernel: reduction length k a multiple of 8 and a product small enough for it to win."""
+    if not (LINEAR_KERNEL and cfg.kd == cfg.kh == cfg.kw == 1 and cfg.stride == 1 and not cfg.ups and
+            cfg.pad_h == 0 and cfg.pad_w == 0 and k % 8 == 0):
+        return False
+    return rows is None or 2.0 * rows * n * k <= LINEAR_MAX_FLOP
+
+
+def _linear_raw(a, wpack, bias, res, out, M, N, K, ns, a_view=None, c_view=None):
+    """out[m][n] = sum_k a[m][k] * W[n][k] (+ bias) (+ res); a_view / c_view: optional (tm, bs, ts, ck, ks) strided
+    views (see vca_lin_desc); default: plain row-major matrices."""
+    atm, abs_, ats, ack, aks = a_view if a_view is not None else (M, 0, K, K, 0)
+    ctm, cbs, cts, ccn, cns = c_view if c_view is not None else (M, 0, N, N, 0)
+    d = _lib.LinDesc(M, N, K, atm, ack, abs_, ats, aks, ctm, ccn, cbs, cts, cns)
+    check(_lib.lib().vca_linear_bf16(ctypes.byref(d), ns, ptr(a), wpack.data_ptr(), ptr(bias), ptr(res), ptr(out),
+                                     stream()), 'linear_bf16')
+    return out
+
+
 def _conv_fwd_raw(x, w, bias, cfg, stats=None):
     """stats: optional zeroed (2, Cout) tensor receiving per-channel sum / sum of squares of (y - bias)."""
     y = torch.empty(cfg.yshape, device=x.device, dtype=torch.float32)
     d = cfg.desc()
     ns = _nsplit(_grad_conv[0])
+    if ns and stats is None and _pointwise(cfg, cfg.cin, x.numel() // cfg.cin, cfg.cout):
+        return _linear_raw(x, _pack(w, 10), bias, None, y, x.numel() // cfg.cin, cfg.cout, cfg.cin, ns)
     if ns and cfg.cin > 1 and cfg.kd == 1:
         ws, nws = (None, 0) if stats is not None else _split_ws(cfg, 'fwd', d, x.device)
         check(_lib.lib().vca_conv_fwd_bf16_ws(d, ns, ptr(x), _pack(w, 10).data_ptr(), ptr(bias), None, None, None, None,
@@ -295,6 +327,9 @@ def _conv_dgrad_raw(gy, w, cfg, res=None):
     ns = _nsplit(True)
     fuse = res is not None and not cfg.ups
     r = _c(res) if fuse else None
+    if ns and cfg.cout > 1 and _pointwise(cfg, cfg.cout, gy.numel() // cfg.cout, cfg.cin):
+        _linear_raw(gy, _pack(w, 11), None, r, gx, gy.numel() // cfg.cout, cfg.cin, cfg.cout, ns)
+        return gx.view(cfg.xshape)
     if ns and cfg.subpixel_dgrad():
         d = cfg.subpixel_dgrad_desc()
         ws, nws = (None, 0) if fuse else _split_ws(cfg, 'dgrad2', d, gy.device)
