@@ -57,6 +57,31 @@ def _time(fn, reps=5, warm=2):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def _time_graph(fn, reps=10, replays=3):
+    """Device time of fn() (seconds) with `reps` calls captured into one HIP graph and replayed: what the call costs
+    inside a replayed training step.  Issued from Python a chain of short launches measures the interpreter (about
+    13 us per launch here), not the GPU."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * replays) * 1e-3
+
+
 def roofline_probe(device, dtype):
     """Time the dominant kernel (the implicit-GEMM convolution, forward = split product in both 'bf16x3' and 'mixed')
     on the largest layer the step runs, decode.0.conv2 (5x5, 512->512 on the 20x75 map of 32 clips; decode.0.conv1
@@ -96,7 +121,7 @@ def north_star_probes(device, models):
     vid = torch.randn(B, 1, T, H, H, device=device)
     with torch.no_grad():
         xs = vid.permute(0, 2, 3, 4, 1).contiguous()                # (B, T, H, W, 1) channels-last
-        dt = _time(lambda: vf.front(xs))
+        dt = _time_graph(lambda: vf.front(xs), reps=5)
     oh = H // 4
     # algorithmic bytes of a1 + a2 as one stage: the clip once, the pooled map it hands to the ResNet trunk and one
     # argmax byte per pooled element for the backward pass (the full-resolution stem output is an implementation
@@ -118,14 +143,17 @@ def north_star_probes(device, models):
     g1 = torch.randn(B, 20, T, 128, device=device)
     lens = torch.full((B,), T, device=device, dtype=torch.int32)
     with torch.no_grad():
-        dt = _time(lambda: att(ctx, g1, lens))
+        dt = _time_graph(lambda: att(ctx, g1, lens))
+        dt_eager = _time(lambda: att(ctx, g1, lens))
     S, Tq, D = T, T, 256
     fl = 2.0 * B * (2 * S * 512 * D + Tq * 2560 * D + 2 * Tq * S * D + Tq * D * 1280)
     peak = PEAK_TFLOPS[ops.get_precision()]
     out['vca_module'] = dict(stage='att1: k/v/q/out projections + QK^T + mask + softmax + AV', ms=round(dt * 1e3, 3),
                              gflop=round(fl / 1e9, 2), achieved_TFLOPs=round(fl / dt / 1e12, 1), peak_TFLOPs=peak,
                              frac=round(fl / dt / 1e12 / peak, 4),
-                             qk_av_share_of_flops=round(2.0 * B * 2 * Tq * S * D / fl, 3))
+                             qk_av_share_of_flops=round(2.0 * B * 2 * Tq * S * D / fl, 3),
+                             timing='device time under graph replay (as inside a replayed step); issued launch by '
+                                    'launch from Python the same call takes %.3f ms, host-bound' % (dt_eager * 1e3))
     return out
 
 
