@@ -170,6 +170,14 @@ typedef struct vca_lin_desc {
 } vca_lin_desc;
 int vca_linear_bf16(const vca_lin_desc* d, int nsplit, const float* a, const void* wpack, const float* bias,
                     const float* res, float* c, void* stream);
+/* The same product for shapes of a few GFLOP (attention projections generator.py:145-148,167, GRU input products
+ * visual_front.py:20, the sync discriminator's Linear generator.py:335): 128 x 128 tiles through a three-stage LDS
+ * ring.  With few tiles the reduction is split over workgroups and the partial tiles go through ws
+ * (ws_floats >= vca_gemm_bf16_ws_floats(d) fp32 values, 16-byte aligned, contents irrelevant before and after; the
+ * query returns 0 for a descriptor that does not split, and ws may then be NULL). */
+long long vca_gemm_bf16_ws_floats(const vca_lin_desc* d);
+int vca_gemm_bf16(const vca_lin_desc* d, int nsplit, const float* a, const void* wpack, const float* bias,
+                  const float* res, float* c, float* ws, long long ws_floats, void* stream);
 
 /* Conv3d stem of the visual front-end (nn.Conv3d(1, 64, (5,7,7), (1,2,2), (2,3,3), bias=False),
  * visual_front.py:11) in split-bf16: x is the single-channel video [B][T][H][W], y the channels-last feature map

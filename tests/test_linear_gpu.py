@@ -27,11 +27,15 @@ SHAPES = [(2400, 256, 2560), (32, 1, 512), (33, 321, 256), (4800, 1280, 256), (7
 
 
 @gpu
+@pytest.mark.parametrize('kernel', ['skinny', 'tiled'])
 @pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 2e-2)])
 @pytest.mark.parametrize('M,N,K', SHAPES)
-def test_linear_forward_and_gradients(M, N, K, prec, tol):
+def test_linear_forward_and_gradients(M, N, K, prec, tol, kernel, monkeypatch):
     from vcagan_amd import ops
     ops.set_precision(prec)
+    # every shape through each of the two kernels (by default the product's size decides)
+    monkeypatch.setattr(ops, 'LINEAR_MAX_FLOP', 1e30 if kernel == 'skinny' else 0.0)
+    monkeypatch.setattr(ops, '_tiled_wins', lambda rows, n, k: kernel == 'tiled')
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / K ** 0.5
@@ -76,17 +80,20 @@ def test_linear_strided_views():
     w = (torch.randn(N, Fq * C, generator=g) / (Fq * C) ** 0.5).cuda()       # columns ordered (f, c)
     bias = torch.randn(N, generator=g).cuda()
     out = torch.empty(B * T, N, device='cuda')
-    ops._linear_raw(x, ops._pack(w, 10), bias, None, out, B * T, N, Fq * C, 3,
-                    a_view=(T, Fq * T * C, C, C, T * C))
     want = x.permute(0, 2, 1, 3).reshape(B * T, Fq * C).double() @ w.double().t() + bias.double()
-    assert rel_err(out, want) < 1e-4
-    # output projection: rows (b, t), columns (f, c') scattered into the map (B, F, T, C')
     w2 = (torch.randn(Fq * Co, N, generator=g) / N ** 0.5).cuda()
-    ymap = torch.zeros(B, Fq, T, Co, device='cuda')
-    ops._linear_raw(out, ops._pack(w2, 10), None, None, ymap, B * T, Fq * Co, N, 3,
-                    c_view=(T, Fq * T * Co, Co, Co, T * Co))
-    want2 = (out.double() @ w2.double().t()).view(B, T, Fq, Co).permute(0, 2, 1, 3)
-    assert rel_err(ymap, want2) < 1e-4
+    res = torch.randn(B, Fq, T, Co, generator=g).cuda()
+    for tiled in (False, True):
+        out = torch.empty(B * T, N, device='cuda')
+        ops._linear_raw(x, ops._pack(w, 10), bias, None, out, B * T, N, Fq * C, 3,
+                        a_view=(T, Fq * T * C, C, C, T * C), tiled=tiled)
+        assert rel_err(out, want) < 1e-4, tiled
+        # output projection: rows (b, t), columns (f, c') scattered into the map (B, F, T, C'), residual laid out alike
+        ymap = torch.zeros(B, Fq, T, Co, device='cuda')
+        ops._linear_raw(out, ops._pack(w2, 10), None, res, ymap, B * T, Fq * Co, N, 3,
+                        c_view=(T, Fq * T * Co, Co, Co, T * Co), tiled=tiled)
+        want2 = (out.double() @ w2.double().t()).view(B, T, Fq, Co).permute(0, 2, 1, 3) + res.double()
+        assert rel_err(ymap, want2) < 1e-4, tiled
 
 
 def test_linear_rejects_descriptors_it_cannot_take():

@@ -79,6 +79,8 @@ _SIGS = {
     'vca_pack_weight_bf16': ([_I, _I, _I, _I, _P, _P, _P], _I),
     'vca_pack_weight_bf16_batch': ([_P, _I, _I, _I, _P], _I),
     'vca_linear_bf16': ([ctypes.POINTER(LinDesc), _I, _P, _P, _P, _P, _P, _P], _I),
+    'vca_gemm_bf16_ws_floats': ([ctypes.POINTER(LinDesc)], _LL),
+    'vca_gemm_bf16': ([ctypes.POINTER(LinDesc), _I, _P, _P, _P, _P, _P, _P, _LL, _P], _I),
     'vca_stem_pack_weight': ([_P, _P, _P], _I),
     'vca_stem_pack_bytes': ([], _LL),
     'vca_stem_fwd_bf16': ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], _I),

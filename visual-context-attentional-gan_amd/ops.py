@@ -288,15 +288,38 @@ def _pointwise(cfg, k, rows=None, n=None):
     if not (LINEAR_KERNEL and cfg.kd == cfg.kh == cfg.kw == 1 and cfg.stride == 1 and not cfg.ups and
             cfg.pad_h == 0 and cfg.pad_w == 0 and k % 8 == 0):
         return False
-    return rows is None or 2.0 * rows * n * k <= LINEAR_MAX_FLOP
+    return rows is None or 2.0 * rows * n * k <= LINEAR_MAX_FLOP or _tiled_wins(rows, n, k)
 
 
-def _linear_raw(a, wpack, bias, res, out, M, N, K, ns, a_view=None, c_view=None):
+GEMM_KERNEL = __import__('os').environ.get('VCA_GEMM', '1') != '0'   # False: large pointwise products on the conv kernel
+_gemm_ws = {}    # (M, N, K, views) -> workspace floats of the tiled kernel's reduction split
+
+
+def _tiled_wins(rows, n, k):
+    """Large pointwise products where the 128 x 128 LDS-ring kernel measured shorter than the convolution kernel: a
+    reduction of at least 16 chunks of 32 and at most two rounds of tiles over the 256 CUs (beyond that the convolution
+    kernel's two workgroups per CU hide the short reduction's prologue better)."""
+    return GEMM_KERNEL and k >= 512 and ((rows + 127) // 128) * ((n + 127) // 128) <= 512
+
+
+def _linear_raw(a, wpack, bias, res, out, M, N, K, ns, a_view=None, c_view=None, tiled=None):
     """out[m][n] = sum_k a[m][k] * W[n][k] (+ bias) (+ res); a_view / c_view: optional (tm, bs, ts, ck, ks) strided
-    views (see vca_lin_desc); default: plain row-major matrices."""
+    views (see vca_lin_desc); default: plain row-major matrices.  tiled: True = the 128 x 128 LDS-ring kernel, False =
+    the LDS-free skinny kernel, None = by size."""
     atm, abs_, ats, ack, aks = a_view if a_view is not None else (M, 0, K, K, 0)
     ctm, cbs, cts, ccn, cns = c_view if c_view is not None else (M, 0, N, N, 0)
     d = _lib.LinDesc(M, N, K, atm, ack, abs_, ats, aks, ctm, ccn, cbs, cts, cns)
+    if tiled is None:
+        tiled = 2.0 * M * N * K > LINEAR_MAX_FLOP and _tiled_wins(M, N, K)
+    if tiled:
+        key = (M, N, K, a_view, c_view)
+        n = _gemm_ws.get(key)
+        if n is None:
+            n = _gemm_ws[key] = int(_lib.lib().vca_gemm_bf16_ws_floats(ctypes.byref(d)))
+        ws = torch.empty(n, device=out.device, dtype=torch.float32) if n else None
+        check(_lib.lib().vca_gemm_bf16(ctypes.byref(d), ns, ptr(a), wpack.data_ptr(), ptr(bias), ptr(res), ptr(out),
+                                       ptr(ws), n, stream()), 'gemm_bf16')
+        return out
     check(_lib.lib().vca_linear_bf16(ctypes.byref(d), ns, ptr(a), wpack.data_ptr(), ptr(bias), ptr(res), ptr(out),
                                      stream()), 'linear_bf16')
     return out
