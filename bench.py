@@ -425,8 +425,11 @@ def main():
             res['exchange_ms'] = {'d_side': round(ex[0], 3), 'g_side': round(ex[1], 3),
                                   'bytes': [int(sum(g.numel() for g in e.gflats) * 4)
                                             for e in (step.d_exchange, step.g_exchange)],
-                                  'note': 'per step on rank 0, HIP events on the compute stream around each side\'s '
-                                          'mean all-reduce (issued between the per-phase graphs, nothing overlapped)'}
+                                  'schedule': 'overlapped' if step.overlap else 'blocking',
+                                  'note': 'per step on rank 0, HIP events on the compute stream around its wait for '
+                                          'each side\'s mean all-reduce (issued between the per-phase graphs; the '
+                                          'overlapped schedule, VCA_EXCHANGE_OVERLAP=1, starts them slice by slice '
+                                          'beside the phases that do not need them)'}
         res['roofline'] = roofline_probe(device, dtype)
         res['dtype_note'] = DTYPE_NOTE.get(dtype, dtype)
         if world == 1 and not lrs:

@@ -1,5 +1,5 @@
 """One rank of the two-process data-parallel rehearsal (tests/test_dp_two_ranks_gpu.py): the training step's
-multi-rank code path (per-rank seeds, initial broadcast, three per-phase graphs with the two gradient all-reduces
+multi-rank code path (per-rank seeds, initial broadcast, the per-phase graphs with the gradient all-reduces
 between them) with a live process group.  Both ranks use the same GPU, so the collective backend is gloo (two RCCL
 ranks on one device cannot make progress); everything else is what a one-GPU-per-rank RCCL job runs.
 usage: dp_worker.py RANK WORLD PORT OUT.pt"""
@@ -50,7 +50,8 @@ def main():
         b = fixtures.make_batch(2, 20, 96, 100 + rank, [20, 14 + rank])      # each rank its own shard
         d = {k: (v.cuda() if k != 'vid_len' else v) for k, v in b.items()}
         gs = train_step.GraphedStep(step, d['mel'], d['spec'], d['vid'], d['vid_len'], 'device', warmup=1)
-        assert gs.segmented and len(gs.graphs) == 3
+        assert step.overlap == (os.environ.get('VCA_EXCHANGE_OVERLAP') == '1')
+        assert gs.segmented and len(gs.graphs) == (5 if step.overlap else 3)
         _log('captured')
         losses = []
         for _ in range(2):

@@ -96,6 +96,17 @@ def _worker_models(rank, world, port, q):
             ex.reduce()
             want = [1.5 * (i % 7 + 1) for i in range(len(params))]
             err = max(float((p.grad - w).abs().max()) for p, w in zip(params, want))
+            # the same exchange slice by slice (one network at a time, as the overlapped schedule starts them)
+            for i, p in enumerate(params):
+                p.grad.fill_(float((rank + 1) * (i % 7 + 1)))
+            nets = [gf for _, gf in flats]
+            assert sum(g.numel() for g in nets) == allg.numel()
+            assert all(a.data_ptr() + a.numel() * 4 == b.data_ptr() for a, b in zip(nets, nets[1:]))
+            for g in nets[1:]:
+                ex.start([g])
+            ex.start(nets[:1])
+            ex.wait()
+            err = max(err, max(float((p.grad - w).abs().max()) for p, w in zip(params, want)))
             out[side] = (len(params), allg.numel(), err)
         q.put((rank, out))
     finally:

@@ -1,6 +1,7 @@
 """The data-parallel training step with two live ranks (the reference's counterpart is nn.DataParallel,
-train.py:112-119).  Two processes, one shard of the batch each, run the captured three-graph step with the two
-gradient exchanges between the graphs.  Only one GPU is available to the tests, so both ranks share it and the
+train.py:112-119).  Two processes, one shard of the batch each, run the captured per-phase graphs with the gradient
+exchanges between them, in both schedules (three graphs and one blocking collective per side; five graphs with the
+collectives started slice by slice).  Only one GPU is available to the tests, so both ranks share it and the
 exchange runs over gloo; the orchestration (seeding, broadcast, segmented replay, exchange points) is the one an
 RCCL job with a GPU per rank runs."""
 import os
@@ -24,11 +25,13 @@ def _free_port():
 
 
 @gpu
-def test_two_ranks_stay_in_step(tmp_path):
+@pytest.mark.parametrize('overlap', ['0', '1'])
+def test_two_ranks_stay_in_step(tmp_path, overlap):
     port = str(_free_port())
     outs = [str(tmp_path / ('rank%d.pt' % r)) for r in range(2)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(r), '2', port, outs[r]],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, VCA_EXCHANGE_OVERLAP=overlap)) for r in range(2)]
     logs = []
     try:
         for p in procs:

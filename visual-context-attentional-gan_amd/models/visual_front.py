@@ -19,7 +19,7 @@ class Visual_front(nn.Module):
         self.dropout = nn.Dropout(0.3)
         self.sentence_encoder = nn.GRU(512, 512, 2, bidirectional=True, dropout=0.3)
         self.fc = nn.Linear(1024, 512)
-        self.defer_sentence = False     # see forward(); set by a caller that waits for the sentence features itself
+        self.defer_sentence = False     # see sentence(); set by a caller that waits for the sentence features itself
 
     def front(self, x):
         """The 3-D front-end (visual_front.py:11-14,25-27): x (B, T, H, W, 1) channels-last clip -> (B*T, H/4, W/4, 64)
@@ -30,12 +30,16 @@ class Visual_front(nn.Module):
         return ops.bn_act_maxpool3(f.view(B * T, f.shape[2], f.shape[3], 64), self.frontend[1], self.frontend[2],
                                    stats=stats)
 
-    def forward(self, x):
-        """x: (B, 1, T, H, W) video.  Returns phonemes (B, T, 512) and sentence features (B, 512, T)."""
+    def trunk(self, x):
+        """x: (B, 1, T, H, W) video -> phoneme features (B, T, 512): front-end, ResNet-18, dropout
+        (visual_front.py:25-31)."""
         B, _, T, H, W = x.shape
         f = self.front(x.reshape(B, T, H, W, 1))
         f = self.resnet(f)                                                           # (B*T, 512)
-        f = ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
+        return ops.dropout(f, self.dropout.p, self.training).view(B, T, 512)
+
+    def sentence(self, f):
+        """Sentence features (B, 512, T) of the phoneme features (visual_front.py:32-36)."""
         if getattr(self, 'defer_sentence', False) and f.is_cuda:
             # The recurrence is 2 x T launches of a few microseconds each, and the decoder does not read the sentence
             # features before its first attention module: on a side stream it runs beside the decoder's first blocks
@@ -46,8 +50,13 @@ class Visual_front(nn.Module):
             with torch.cuda.stream(side):
                 sent = self._sentence(f)
             sent._vca_stream = side
-            return f, sent
-        return f, self._sentence(f)
+            return sent
+        return self._sentence(f)
+
+    def forward(self, x):
+        """x: (B, 1, T, H, W) video.  Returns phonemes (B, T, 512) and sentence features (B, 512, T)."""
+        f = self.trunk(x)
+        return f, self.sentence(f)
 
     def _sentence(self, f):
         sent = ops.gru(f, self.sentence_encoder, self.training)                      # (B, T, 1024)

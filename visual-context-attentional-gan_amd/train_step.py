@@ -9,6 +9,7 @@ gradients (which for v_front include the sync-loss contribution of the D phase) 
 Batch-norm statistics stay per replica, as they do under DataParallel.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -110,8 +111,10 @@ class _Heads:
 class GanStep:
     """Callable running one full G+D step; variant 'grid' = train.py, 'lrs' = train_LRS.py."""
 
-    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False, ctc=None):
-        """ctc: None, or dict(front=Audio_front, back=Backend, weight=w): the multi-task configuration (BASELINE
+    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False, ctc=None, overlap=None):
+        """overlap: run the gradient exchanges beside the parts of the step that do not need their results (only
+        with an active exchange; default: off, VCA_EXCHANGE_OVERLAP=1 turns it on); see schedule().
+        ctc: None, or dict(front=Audio_front, back=Backend, weight=w): the multi-task configuration (BASELINE
         configs[4]) adds w * CTC(ASR scorer(g3), text) to gen_loss.  The reference ships that scorer for inference only
         (ASR_model/GRID/test.py) and has no such training term, so this one is defined here: the scorer is frozen and
         in eval mode, it reads the generated mel g3 as it is, its frame rate is the video's (mel frames / 4), the loss
@@ -128,6 +131,9 @@ class GanStep:
         self.gflat = {n: gf for opt in optimizers for n, (_, gf) in opt.flats.items()}
         self.d_exchange = GradExchange([self.d_opt.all_grads], group=group, force=force_exchange)
         self.g_exchange = GradExchange([self.g_opt.all_grads], group=group, force=force_exchange)
+        if overlap is None:
+            overlap = os.environ.get('VCA_EXCHANGE_OVERLAP', '0') == '1'
+        self.overlap = bool(overlap) and self.g_exchange.active
         self._seeds = {}
         if dist.is_available() and dist.is_initialized():
             ops.set_seed(torch.initial_seed(), dist.get_rank(group))   # each replica draws its own dropout masks
@@ -181,14 +187,55 @@ class GanStep:
     def __call__(self, mel, spec, vid, vid_len, noise=None, text=None, text_len=None):
         """mel (B,1,80,4T) in [-1,1], spec (B,1,321,4T), vid (B,1,T,H,W), all on the device; vid_len: lengths.
         text (B, Lmax) class ids and text_len (B,): the transcripts, with ctc= only."""
+        sched = self.schedule()
         self.d_phase(mel, spec, vid, vid_len, noise, text, text_len)
-        self.d_exchange.reduce()
-        self.g_phase()
-        self.g_exchange.reduce()
-        return self.finish()
+        sched[0][1]()
+        for phase, exchange in sched[1:]:
+            phase()
+            exchange()
+        return self._out
 
-    # The step is three device-only phases separated by the two gradient exchanges, so that a caller can replay
-    # each phase as one HIP graph and keep the collectives outside the graphs.
+    def g_slices(self, *names):
+        """The named networks' gradients as contiguous runs of the generator side's flat buffer (neighbours merged)."""
+        flat = self.g_opt.all_grads
+        runs = []
+        for n in names:
+            g = self.gflat[n]
+            off = (g.data_ptr() - flat.data_ptr()) // flat.element_size()
+            if runs and runs[-1][1] == off:
+                runs[-1][1] = off + g.numel()
+            else:
+                runs.append([off, off + g.numel()])
+        return [flat[a:b] for a, b in runs]
+
+    def schedule(self):
+        """The step as (phase, exchange) pairs: device-only phases, each followed by the collective calls issued
+        behind it (a caller may replay every phase as one HIP graph and keep the collectives outside the graphs; the
+        first phase is d_phase, which takes the batch).  Without overlap: the reference's order (train.py:209-236 under
+        nn.DataParallel, train.py:112-119), each side's gradients exchanged in one blocking collective.  With overlap
+        the discriminator side's all-reduce runs beside the postnet's forward pass (the one part of the G phase that
+        does not read the updated discriminators), and the generator side's is split where its backward pass is:
+        generator + postnet gradients travel while the visual front-end is still being back-propagated, the front-end's
+        slice follows, and the step waits for both before g_optimizer.step().  The price is two more cuts in a
+        captured step (five graphs instead of three), and a cut costs 0.5-0.9 ms of drained pipeline and lost
+        cross-phase overlap: a single-rank rehearsal takes 72.1 ms per step this way against 70.2 (69.1 as one graph),
+        which is about what an 8-GPU xGMI node can hide (two 200 MB all-reduces, roughly 1.4 ms each, of which the
+        postnet and the front-end's backward pass cover some 1.8 ms).  Hence off by default; it is meant for
+        exchanges slower than one node's."""
+        def fin():
+            self._out = self.finish()
+        if not self.overlap:
+            return [(self.d_phase, self.d_exchange.reduce), (self.g_phase, self.g_exchange.reduce), (fin, lambda: None)]
+
+        def last():
+            self.g_exchange.start(self.g_slices('v_front'))
+            self.g_exchange.wait()
+        return [(self.d_phase, self.d_exchange.start),
+                (self.g_pre, self.d_exchange.wait),
+                (self.g_main, lambda: self.g_exchange.start(self.g_slices('gen', 'post'))),
+                (self.g_trunk, last),
+                (fin, lambda: None)]
+
     def d_phase(self, mel, spec, vid, vid_len, noise=None, text=None, text_len=None):
         """Forward of the generator side, discriminator losses and their backward (train.py:170-210)."""
         m = self.m
@@ -203,7 +250,15 @@ class GanStep:
         # waited for (ops.ensure_ready) by whoever reads it; the decoder does so before its first attention module.
         m['v_front'].defer_sentence = D_STREAMS
         try:
-            phon, sent = m['v_front'](vid)
+            if self.overlap:
+                # The G phase's backward pass is cut at the phoneme features (g_main / g_trunk): everything downstream
+                # of them, the sentence encoder included, hangs on a leaf.
+                trunk = m['v_front'].trunk(vid)
+                phon = trunk.detach().requires_grad_(True)
+                sent = m['v_front'].sentence(phon)
+            else:
+                trunk = None
+                phon, sent = m['v_front'](vid)
         finally:
             m['v_front'].defer_sentence = False
         g1, g2, g3 = m['gen'](sent, phon, vid_len, noise=noise)
@@ -243,7 +298,7 @@ class GanStep:
         with ops.direct_param_grad(), _quiet_leaf_streams():
             out.backward(self._onehot(5, 0, out.device))
             self._join_dis()
-        self._st = dict(spec=spec, phon=phon, phon_d=phon_d, sd=sd, T=T, g=(g1, g2, g3),
+        self._st = dict(spec=spec, phon=phon, phon_d=phon_d, trunk=trunk, sd=sd, T=T, g=(g1, g2, g3),
                         tgt=[r.detach() for r in reals], dis_loss=out[0].detach(), sync_loss=out[1].detach(),
                         grad_p=out[2:5].detach(), text=text, text_len=text_len, vid_len=vid_len)
 
@@ -259,6 +314,18 @@ class GanStep:
 
     def g_phase(self):
         """d_optimizer.step(), then the generator losses and their backward (train.py:211-235)."""
+        self.g_pre()
+        self.g_main()
+        self.g_trunk()
+
+    def g_pre(self):
+        """With overlap: the postnet's forward pass on g3 (train.py:214), ahead of d_optimizer.step()."""
+        if self.overlap:
+            self._st['gs'] = self.m['post'](self._st['g'][2])
+
+    def g_main(self):
+        """d_optimizer.step(), the generator losses and their backward pass; with overlap the pass ends at the phoneme
+        features and g_trunk() takes it through the visual front-end."""
         m, st = self.m, self._st
         self.d_opt.step()
         g1, g2, g3 = st['g']
@@ -279,7 +346,8 @@ class GanStep:
             tl = ops.as_lens(st['text_len'], logits.device)
             return ops.ctc_nll(logits, st['text'], frames, tl) / tl.clamp(min=1).to(logits.dtype)
 
-        lo, (gs, g_sync) = self._each_dis(branch, lambda: (m['post'](g3), m['s_dis'](phon.detach(), g3, gen=True)),
+        post = (lambda: st['gs']) if 'gs' in st else (lambda: m['post'](g3))
+        lo, (gs, g_sync) = self._each_dis(branch, lambda: (post(), m['s_dis'](phon.detach(), g3, gen=True)),
                                           n=4 if self.ctc is not None else 3)
         gen_lo = lo[:3]
         # slot 0 gen_loss, 1 g_loss, 2 recon_loss, 3 g_sync_loss.  GRID (train.py:222-231): g_loss = adv/3 + g_sync,
@@ -302,16 +370,32 @@ class GanStep:
         # phase's backward stops at the detached generator outputs and at phon_d, so it has added nothing to gen /
         # post; the discriminators' parameters take no gradient in this phase.
         with ops.direct_param_grad(), _quiet_leaf_streams():
-            torch.autograd.backward([out, phon], [self._onehot(out.numel(), 0, out.device), st['phon_d'].grad])
+            if st['trunk'] is None:
+                torch.autograd.backward([out, phon], [self._onehot(out.numel(), 0, out.device), st['phon_d'].grad])
+            else:
+                out.backward(self._onehot(out.numel(), 0, out.device))
             self._join_dis()
         for p in d_params:
             p.requires_grad_(True)
         out = out.detach()
+        cut = (st['trunk'], phon, st['phon_d']) if st['trunk'] is not None else None
         self._st = dict(dis_loss=st['dis_loss'], gen_loss=out[0], sync_loss=st['sync_loss'],
                         g_sync_loss=out[3], recon_loss=out[2], g_loss=out[1],
                         grad_p=st['grad_p'], g1=g1.detach(), g2=g2.detach(), g3=g3.detach(), gs=gs.detach())
         if self.ctc is not None:
             self._st['ctc_loss'] = out[4]
+        self._cut = cut
+
+    def g_trunk(self):
+        """With overlap: the visual front-end's backward pass, from the sum of both phases' gradients at the phoneme
+        features (see d_phase)."""
+        cut, self._cut = getattr(self, '_cut', None), None
+        if cut is None:
+            return
+        trunk, phon, phon_d = cut
+        with ops.direct_param_grad(), _quiet_leaf_streams():
+            trunk.backward(phon.grad + phon_d.grad)
+            self._join_dis()
 
     def finish(self):
         """g_optimizer.step() (train.py:236); returns the step's losses and outputs."""
@@ -324,8 +408,9 @@ class GanStep:
 class GraphedStep:
     """A GanStep captured once into HIP graphs and replayed instead of several thousand kernel launches issued from
     Python per training step.  A single process captures the whole step as one graph; with data parallelism (or
-    segmented=True) the three phases are three graphs sharing one memory pool, replayed in order with the two
-    gradient all-reduces issued between them on the same stream, so no collective is ever captured.  Inputs are
+    segmented=True) the phases of GanStep.schedule() (three, or five with overlapped exchanges) are graphs sharing
+    one memory pool, replayed in order with the gradient all-reduces issued between them from the same stream, so
+    no collective is ever captured.  Inputs are
     copied into static device buffers before each replay; the returned tensors are the graphs' static outputs
     (overwritten by the next call).  Shapes are fixed at capture.
 
@@ -372,15 +457,15 @@ class GraphedStep:
             # Other threads (the process group's watchdog) may touch the device while a phase is being captured.
             mode = 'thread_local' if step.d_exchange.active else 'global'
             pool = torch.cuda.graph_pool_handle() if pool is None else pool
-            self.graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            with torch.cuda.graph(self.graphs[0], pool=pool, capture_error_mode=mode):
-                step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz, s['text'], s['text_len'])
-            step.d_exchange.reduce()         # keeps the ranks' collective sequences aligned; the data is not used
-            with torch.cuda.graph(self.graphs[1], pool=pool, capture_error_mode=mode):
-                step.g_phase()
-            step.g_exchange.reduce()
-            with torch.cuda.graph(self.graphs[2], pool=pool, capture_error_mode=mode):
-                self.out = step.finish()
+            sched = step.schedule()
+            first = lambda: step.d_phase(s['mel'], s['spec'], s['vid'], s['vid_len'], nz, s['text'], s['text_len'])
+            self.exchanges = [ex for _, ex in sched]
+            self.graphs = [torch.cuda.CUDAGraph() for _ in sched]
+            for g, (phase, exchange) in zip(self.graphs, [(first, sched[0][1])] + sched[1:]):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                    phase()
+                exchange()                   # keeps the ranks' collective sequences aligned; the data is not used
+            self.out = step._out
         self.warmup_steps = warmup
 
     def _run(self):
@@ -408,11 +493,9 @@ class GraphedStep:
         if not self.segmented:
             self.graphs[0].replay()
         else:
-            self.graphs[0].replay()
-            self.step.d_exchange.reduce()
-            self.graphs[1].replay()
-            self.step.g_exchange.reduce()
-            self.graphs[2].replay()
+            for g, exchange in zip(self.graphs, self.exchanges):
+                g.replay()
+                exchange()
         return self.out
 
 
