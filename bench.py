@@ -107,7 +107,7 @@ def roofline_probe(device, dtype):
     return dict(bound='mfma', kernel=kern + ' on decode.0.conv2', achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4), issued_mfma_tflops=round(issued, 2),
                 issued_frac=round(issued / peak, 4), traffic=traffic,
-                traffic_source='profiles/r2_decode0conv2_pmc_v3.txt (separate --pmc passes, not this run)'
+                traffic_source='profiles/r3_decode0conv2_pmc.txt (separate --pmc passes, not this run)'
                 if traffic else None, launch_ms=round(dt * 1e3, 3), flops_per_launch=flops)
 
 
