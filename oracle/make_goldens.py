@@ -117,7 +117,9 @@ def vfront_case(rg, rv, name, H, B=1, T=6, seed=21):
     print(name, phon.shape, sent.shape)
 
 
-def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, seed=31):
+def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, seed=31, out_stride=None):
+    """out_stride: None stores the generated mels whole; an integer stores every out_stride-th value of g1 / g2 / g3
+    and of the postnet's spectrogram ('gs') instead, for the benchmark-sized case whose outputs run to megabytes."""
     m = build_reference(rg, rv, 200)
     for k in m:
         m[k].train()
@@ -141,13 +143,15 @@ def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, 
                     out['s%d:dgrad:%s:%s' % (s, mod, pname)] = np32(p.grad).reshape(-1)[idx]
                     gn += float(p.grad.double().pow(2).sum())
                 out['s%d:dgradnorm:%s' % (s, mod)] = np.float64(gn ** 0.5)
-            out['s%d:dphon' % s] = np32(phon.grad)
+            dp = np32(phon.grad)
+            out['s%d:dphon' % s] = dp if not out_stride else dp.reshape(-1)[::out_stride].copy()
         res = cpu_ref.gan_step(drive, opts, b, variant=variant, noise=b['noise'], on_d_backward=d_side)
         for k in ('dis_loss', 'gen_loss', 'sync_loss', 'g_sync_loss', 'recon_loss', 'g_loss'):
             out['s%d:%s' % (s, k)] = np.float64(res[k])
         out['s%d:grad_p' % s] = np.array(res['grad_p'], dtype=np.float64)
-        for k in ('g1', 'g2', 'g3'):
-            out['s%d:%s' % (s, k)] = np32(res[k])
+        for k in ('g1', 'g2', 'g3') + (('gs',) if out_stride else ()):
+            v = np32(res[k])
+            out['s%d:%s' % (s, k)] = v if not out_stride else v.reshape(-1)[::out_stride].copy()
         for mod in sorted(m):
             gn, pn = 0.0, 0.0
             for pname, p in m[mod].named_parameters():
@@ -160,7 +164,7 @@ def step_case(rg, rv, name, variant, B=2, T=20, H=112, lens=(20, 13), nsteps=2, 
             out['s%d:gradnorm:%s' % (s, mod)] = np.float64(gn ** 0.5)
             out['s%d:paramnorm:%s' % (s, mod)] = np.float64(pn ** 0.5)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), B=B, T=T, H=H, lens=np.array(lens), seed=seed,
-                        wseed=200, nsteps=nsteps, variant=variant, **out)
+                        wseed=200, nsteps=nsteps, variant=variant, out_stride=out_stride or 0, **out)
     print(name, {k: float(v) for k, v in out.items() if k.endswith('_loss')})
 
 
@@ -194,6 +198,15 @@ def traj_case(rg, rv, name, variant='grid', B=2, T=20, H=112, lens=(20, 13), nst
                         wseed=200, nsteps=nsteps, variant=variant, eps=eps, nper=nper, **out)
 
 
+def full_case(rg, rv):
+    """One reference step at the benchmark's batch and clip length (BASELINE configs[1]: batch 32, 75 frames,
+    full-length clips) on 112 x 112 crops, the size the reference trains on: its ResNet ends in AvgPool2d(4)
+    (resnet.py:82), which rejects the 3 x 3 maps that 96 x 96 crops leave, so the reference cannot run the
+    benchmark's 96 x 96 itself.  Needs about 55 GB of host memory and two minutes of CPU time; not part of the
+    default run."""
+    step_case(rg, rv, 'step_full', 'grid', B=32, T=75, H=112, lens=(75,) * 32, nsteps=1, seed=51, out_stride=13)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -205,6 +218,8 @@ def main():
             step_case(rg, rv, 'step_lrs', 'lrs')
         if 'traj' in only:
             traj_case(rg, rv, 'traj_grid')
+        if 'full' in only:
+            full_case(rg, rv)
         return
     forward_case(rg, rv, 'fwd_eval', train=False)
     forward_case(rg, rv, 'fwd_train', train=True)

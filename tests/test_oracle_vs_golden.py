@@ -94,6 +94,21 @@ def test_step_matches_reference(variant):
             check_step(m, res, g, s, loss_rtol=1e-3, out_atol=3e-2, grad_rel=0.5, param_p90=2.1e-4)
 
 
+@pytest.mark.skipif(os.environ.get('VCA_BIG_ORACLE') != '1',
+                    reason='needs about 55 GB of host memory and two minutes (VCA_BIG_ORACLE=1 runs it)')
+def test_benchmark_sized_step_matches_reference():
+    """The oracle against the fixture written from the reference at the benchmark's batch and clip length (32 x 75
+    frames of 112 x 112, oracle/make_goldens.py full_case).  Off by default: the CPU suite has to fit a small box."""
+    g = load('step_full')
+    m = fixtures.fill_models(cpu_ref.build_models(), int(g['wseed']))
+    for k in m:
+        m[k].train()
+    b = fixtures.make_batch(int(g['B']), int(g['T']), int(g['H']), int(g['seed']), list(g['lens']))
+    d_side = lambda mods, phon: check_d_side(mods, phon.grad, g, 0, 3e-2, names=cpu_ref.D_NAMES + ('v_front',))
+    res = cpu_ref.gan_step(m, cpu_ref.build_optimizers(m), b, variant='grid', noise=b['noise'], on_d_backward=d_side)
+    check_step(m, res, g, 0, loss_rtol=2e-5, out_atol=1e-5, grad_rel=3e-2, param_p90=5e-6)
+
+
 def test_trajectory_matches_reference():
     """The first steps of the 8-step reference trajectory (tests/golden/traj_grid.npz, run a): the restatement stays
     inside the envelope the reference itself shows between two runs whose clips differ by 1e-6 (run b)."""
