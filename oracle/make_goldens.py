@@ -205,6 +205,9 @@ def full_case(rg, rv):
     benchmark's 96 x 96 itself.  Needs about 55 GB of host memory and two minutes of CPU time; not part of the
     default run."""
     step_case(rg, rv, 'step_full', 'grid', B=32, T=75, H=112, lens=(75,) * 32, nsteps=1, seed=51, out_stride=13)
+    # BASELINE configs[3]: the train_LRS.py step on a batch of 16 variable-length clips padded to 150 frames
+    lens = (150, 143, 131, 127, 118, 109, 101, 96, 88, 80, 73, 67, 59, 52, 46, 40)
+    step_case(rg, rv, 'step_full_lrs', 'lrs', B=16, T=150, H=112, lens=lens, nsteps=1, seed=52, out_stride=13)
 
 
 def main():

@@ -229,9 +229,12 @@ def test_full_size_step_eager_vs_replay():
 
 @gpu
 @pytest.mark.parametrize('prec', ['mixed', 'bf16x3'])
-def test_benchmark_sized_step_matches_reference(prec):
-    """One step at the benchmark's batch and clip length (32 clips of 75 frames; BASELINE configs[1]) against a
-    fixture written from the reference itself (oracle/make_goldens.py full_case), in the benchmark's precision and in
+@pytest.mark.parametrize('name,variant,shape', [('step_full', 'grid', (32, 75, 112)),
+                                                ('step_full_lrs', 'lrs', (16, 150, 112))])
+def test_benchmark_sized_step_matches_reference(name, variant, shape, prec):
+    """One step at the benchmark's batch and clip length (32 clips of 75 frames, train.py's step; BASELINE
+    configs[1]) and one of train_LRS.py's step on 16 clips of 40-150 valid frames padded to 150 (configs[3]) against
+    fixtures written from the reference itself (oracle/make_goldens.py full_case), in the benchmark's precision and in
     the three-product one: losses, R1 terms, sampled generator / postnet outputs (the mel-L1 gate is 1e-3), the
     gradients both optimizers consume and the parameters after Adam.  The crops are 112 x 112, the reference's training
     size: its ResNet ends in AvgPool2d(4) (resnet.py:82) and cannot take the 3 x 3 maps of the benchmark's 96 x 96
@@ -239,17 +242,17 @@ def test_benchmark_sized_step_matches_reference(prec):
     from parity_util import check_d_side, check_step, load, measure_step
     from vcagan_amd import ops, train_step
     ops.set_precision(prec)
-    g = load('step_full')
+    g = load(name)
     B, T, H = int(g['B']), int(g['T']), int(g['H'])
-    assert (B, T, H) == (32, 75, 112)
+    assert (B, T, H) == shape and str(g['variant']) == variant
     m = fixtures.fill_models(train_step.build_models(), int(g['wseed']))
     for k in m:
         m[k].cuda().train()
-    step = train_step.GanStep(m, train_step.build_optimizers(m), 'grid')
+    step = train_step.GanStep(m, train_step.build_optimizers(m, amsgrad=(variant == 'grid')), variant)
     b = _dev(fixtures.make_batch(B, T, H, int(g['seed']), list(g['lens'])))
     step.d_phase(b['mel'], b['spec'], b['vid'], b['vid_len'], b['noise'])
     mt = check_d_side(m, step._st['phon_d'].grad, g, 0, 3e-2)
-    print(prec, 'D side', {k: round(v, 4) for k, v in mt.items()})
+    print(prec, variant, 'D side', {k: round(v, 4) for k, v in mt.items()})
     step.g_phase()
     res = step.finish()
     res = {k: (v.item() if v.numel() == 1 else v.cpu()) for k, v in res.items()}
@@ -257,7 +260,7 @@ def test_benchmark_sized_step_matches_reference(prec):
     check_step(m, res, g, 0, loss_rtol=5e-4, out_atol=3e-3, grad_rel=0.15, param_p90=2.1e-4,
                skip_grads=('dis1', 'dis2', 'dis3', 's_dis'))
     mt = measure_step(m, res, g, 0, ('dis1', 'dis2', 'dis3', 's_dis'))
-    print(prec, {k: float('%.3g' % v) for k, v in mt.items()})
+    print(prec, variant, {k: float('%.3g' % v) for k, v in mt.items()})
     assert max(mt['out_l1:' + k] for k in ('g1', 'g2', 'g3', 'gs')) <= 3e-4        # a third of the 1e-3 gate
 
 

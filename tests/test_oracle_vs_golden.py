@@ -96,16 +96,19 @@ def test_step_matches_reference(variant):
 
 @pytest.mark.skipif(os.environ.get('VCA_BIG_ORACLE') != '1',
                     reason='needs about 55 GB of host memory and two minutes (VCA_BIG_ORACLE=1 runs it)')
-def test_benchmark_sized_step_matches_reference():
-    """The oracle against the fixture written from the reference at the benchmark's batch and clip length (32 x 75
-    frames of 112 x 112, oracle/make_goldens.py full_case).  Off by default: the CPU suite has to fit a small box."""
-    g = load('step_full')
+@pytest.mark.parametrize('name,variant', [('step_full', 'grid'), ('step_full_lrs', 'lrs')])
+def test_benchmark_sized_step_matches_reference(name, variant):
+    """The oracle against the fixtures written from the reference at the benchmark's batch and clip length (32 x 75
+    frames of 112 x 112, train.py's step; 16 ragged clips padded to 150 frames, train_LRS.py's;
+    oracle/make_goldens.py full_case).  Off by default: the CPU suite has to fit a small box."""
+    g = load(name)
     m = fixtures.fill_models(cpu_ref.build_models(), int(g['wseed']))
     for k in m:
         m[k].train()
     b = fixtures.make_batch(int(g['B']), int(g['T']), int(g['H']), int(g['seed']), list(g['lens']))
     d_side = lambda mods, phon: check_d_side(mods, phon.grad, g, 0, 3e-2, names=cpu_ref.D_NAMES + ('v_front',))
-    res = cpu_ref.gan_step(m, cpu_ref.build_optimizers(m), b, variant='grid', noise=b['noise'], on_d_backward=d_side)
+    res = cpu_ref.gan_step(m, cpu_ref.build_optimizers(m, amsgrad=(variant == 'grid')), b, variant=variant,
+                           noise=b['noise'], on_d_backward=d_side)
     check_step(m, res, g, 0, loss_rtol=2e-5, out_atol=1e-5, grad_rel=3e-2, param_p90=5e-6)
 
 
