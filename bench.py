@@ -22,13 +22,21 @@ if ROOT not in sys.path:
 
 B, T, H = 32, 75, 96
 FLOP_PER_FRAME = 9.84e9          # full step at 96x96, counted on the reference with torch's FlopCounterMode
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'mixed': 2500.0}
-MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'mixed': 3}
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'mixed': 2500.0,
+               'fp16': 2500.0, 'fp16x3': 2500.0, 'fp16-mixed': 2500.0}
+MFMA_PER_PRODUCT = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'mixed': 3, 'fp16': 1, 'fp16x3': 3, 'fp16-mixed': 3}
 DTYPE_NOTE = {
     'mixed': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every forward product and '
              'in the gradient chain whose result is the R1 penalty (a loss value), single bf16 products in the '
              'input/weight gradients incl. the second-order terms of that penalty; everything else fp32',
     'bf16x3': 'bf16 matrix cores, fp32 accumulate: split-bf16 (3 products, ~fp32 accuracy) in every product; '
+              'everything else fp32',
+    'fp16': 'IEEE-half matrix cores, fp32 accumulate, one product everywhere, fp32 master weights, dynamic loss scale '
+            '(device-side, skip-on-overflow); everything else fp32',
+    'fp16-mixed': 'IEEE-half matrix cores, fp32 accumulate: split-half (3 products) in every forward product and the R1 '
+                  'gradient chain, single half products in the input/weight gradients under a dynamic loss scale; '
+                  'everything else fp32',
+    'fp16x3': 'IEEE-half matrix cores, fp32 accumulate: split-half (3 products) in every product, dynamic loss scale; '
               'everything else fp32',
 }
 
@@ -239,7 +247,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra mixed-precision measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying a HIP graph')
-    ap.add_argument('--precision', default='mixed', choices=['fp32', 'bf16x3', 'bf16', 'mixed'])
+    ap.add_argument('--precision', default='mixed', choices=['fp32', 'bf16x3', 'bf16', 'mixed', 'fp16', 'fp16-mixed', 'fp16x3'])
     ap.add_argument('--host-inputs', nargs='?', const='inline', default=None, choices=['inline', 'prefetch'],
                     help='hand every step its inputs as pinned host tensors: the PCIe-inclusive rate, an extra '
                          'measurement.  inline: copied on the compute stream in front of the replay, nothing overlapped; '

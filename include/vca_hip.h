@@ -27,6 +27,12 @@ extern "C" {
 /* Library/ABI version (bumped when a signature changes). */
 int vca_abi_version(void);
 
+/* Element type of the 16-bit matrix operands of this build of the library: 0 = bf16 (libvca_hip.so), 1 = IEEE half
+ * (libvca_hip_f16.so, compiled from the same sources with -DVCA_E16_FP16).  Every "_bf16" entry point below computes
+ * in that type; packed weights are not interchangeable between the two builds.  The reference has no reduced-precision
+ * path (train.py runs fp32 throughout); the half build exists for BASELINE configs[4] "fp16 with loss-scaling". */
+int vca_elem_type(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32).
  * Replaces nn.Conv2d / nn.Conv1d / nn.Linear / nn.Conv3d forward, input-gradient and
@@ -492,6 +498,22 @@ int vca_sync_cos_bwd_f32(int B, int T, int C, const float* v, const float* a, co
 int vca_adam_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, const int* step_dev, const float* lr_dev,
                  void* stream);
+
+/* Dynamic loss scaling for half-precision gradients (no counterpart in the reference, which trains in fp32; the
+ * semantics are those of torch.cuda.amp.GradScaler: skip the optimizer step and halve the scale on overflow, double it
+ * after `interval` clean steps).  All state is in device memory so that a captured step keeps adapting:
+ * scale = float[2] {scale, 1/scale}; state = int[4] {clean steps in a row, overflow flag D side, overflow flag G side,
+ * skipped steps}.
+ *   vca_nonfinite_f32      sets *flag to 1 if any of the n (n % 4 == 0, 16-byte aligned) gradients is Inf / NaN
+ *   vca_loss_scale_count   ++*step_dev unless *flag (the Adam step count of the side, before its launches)
+ *   vca_adam_scaled_f32    vca_adam_f32 on g / scale; a no-op when *flag is up (train.py:211,237 with a scaler)
+ *   vca_loss_scale_update  once per training step, after both optimizers: adapts the scale, clears the flags */
+int vca_nonfinite_f32(long long n, const float* g, int* flag, void* stream);
+int vca_loss_scale_count(int* step_dev, const int* flag, void* stream);
+int vca_adam_scaled_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float beta1,
+                        float beta2, float eps, float weight_decay, const int* step_dev, const float* lr_dev,
+                        const float* scale, const int* flag, void* stream);
+int vca_loss_scale_update(float* scale, int* state, float growth, float backoff, int interval, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,11 +13,13 @@ def test_library_exports_declared_symbols():
     hdr = open(os.path.join(ROOT, 'include', 'vca_hip.h')).read()
     declared = set(re.findall(r'\b(?:int|long long)\s+(vca_\w+)\s*\(', hdr))
     assert declared, 'no declarations parsed'
-    L = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), name
     assert declared == set(_lib.exported_symbols())
-    assert L.vca_abi_version() >= 1
+    # both builds of the sources (bf16 and IEEE-half matrix operands) export the same entry points
+    for path, elem in ((_lib.LIB_PATH, 0), (_lib.LIB_PATH_F16, 1)):
+        L = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(L, name), (path, name)
+        assert L.vca_abi_version() >= 1 and L.vca_elem_type() == elem
 
 
 def _desc(_lib, **kw):

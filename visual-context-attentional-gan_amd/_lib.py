@@ -2,6 +2,10 @@
 
 There is no CPU fallback: importing this module without the built library raises, and every call
 checks the kernel's return code.  Build with `python __graft_entry__.py` (hipcc, gfx950).
+
+The sources are compiled twice: libvca_hip.so computes its 16-bit matrix products in bf16, libvca_hip_f16.so (same
+entry points, -DVCA_E16_FP16) in IEEE half.  lib() returns the one ops.set_precision() selected (ELEM); every
+entry point without matrix products is the same code in both.
 """
 import ctypes
 import os
@@ -12,22 +16,28 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvca_hip.so')
+LIB_PATH_F16 = os.path.join(_HERE, 'libvca_hip_f16.so')
+ELEM = ['bf16']          # element type of the matrix products: 'bf16' or 'fp16' (set by ops.set_precision)
 SOURCES = ('conv_f32.hip', 'conv_bf16.hip', 'pointwise.hip', 'misc.hip', 'rnn.hip', 'attention.hip', 'stem.hip',
            'sync_loss.hip', 'layout.hip', 'audio.hip', 'video.hip', 'ctc.hip', 'wgrad_cin1.hip', 'linear.hip')
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library for gfx950 (cross-compiles without a GPU)."""
+    """Compile every HIP source into the two shared libraries for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'vca_hip.h')]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + srcs
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    procs = []
+    for path, flags in ((LIB_PATH, []), (LIB_PATH_F16, ['-DVCA_E16_FP16'])):
+        if not force and os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(d) for d in deps):
+            continue
+        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC'] + flags + ['-o', path] + srcs
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))          # the two builds side by side
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     return LIB_PATH
 
 
@@ -64,6 +74,7 @@ _F = ctypes.c_float
 _LL = ctypes.c_longlong
 _SIGS = {
     'vca_abi_version': ([], _I),
+    'vca_elem_type': ([], _I),
     'vca_conv_fwd_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 10, _I),
     'vca_conv_wgrad_f32': ([ctypes.POINTER(ConvDesc)] + [_P] * 7, _I),
     'vca_pack_weight_f32': ([_I, _I, _I, _I, _P, _P, _F, _P], _I),
@@ -142,23 +153,30 @@ _SIGS = {
     'vca_loss_heads_fwd_f32': ([_P, _P, _P], _I),
     'vca_loss_heads_bwd_f32': ([_P, _P, _P], _I),
     'vca_adam_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P, _P], _I),
+    'vca_nonfinite_f32': ([_LL, _P, _P, _P], _I),
+    'vca_loss_scale_count': ([_P, _P, _P], _I),
+    'vca_adam_scaled_f32': ([_LL, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P, _P], _I),
+    'vca_loss_scale_update': ([_P, _P, _F, _F, _I, _P], _I),
 }
 
-_lib = None
+_libs = {}
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError('libvca_hip.so is not built (%s); run `python __graft_entry__.py`' % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+    """The library whose matrix products use the element type in ELEM."""
+    L = _libs.get(ELEM[0])
+    if L is None:
+        path = {'bf16': LIB_PATH, 'fp16': LIB_PATH_F16}[ELEM[0]]
+        if not os.path.exists(path):
+            raise RuntimeError('%s is not built (%s); run `python __graft_entry__.py`' % (os.path.basename(path), path))
+        L = ctypes.CDLL(path)
         for name, (args, res) in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        _lib = L
-    return _lib
+        assert L.vca_elem_type() == {'bf16': 0, 'fp16': 1}[ELEM[0]], path
+        _libs[ELEM[0]] = L
+    return L
 
 
 def exported_symbols():

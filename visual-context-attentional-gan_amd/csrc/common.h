@@ -7,6 +7,23 @@
 
 #include "../../include/vca_hip.h"
 
+// Element type of the 16-bit matrix operands.  The library is built twice from the same sources: with bf16
+// (libvca_hip.so: fp32's exponent range, 8 significant bits) and, with -DVCA_E16_FP16, with IEEE half
+// (libvca_hip_f16.so: 11 significant bits, normal range 6.1e-5 .. 65504, so gradients need a loss scale).  Entry
+// points, layouts and kernel names are the same in both; vca_elem_type() tells which one a library is.
+#ifdef VCA_E16_FP16
+typedef _Float16 vca_e16;
+#define VCA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define VCA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define VCA_ELEM_TYPE 1
+#else
+typedef __bf16 vca_e16;
+#define VCA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define VCA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VCA_ELEM_TYPE 0
+#endif
+typedef vca_e16 bf16x8 __attribute__((ext_vector_type(8)));   // 8 operand elements of either type: one MFMA fragment
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -20,7 +20,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128;
 constexpr int MAXPOS = 384;  // halo positions per workgroup (hi + lo images: 48 KiB)
@@ -65,8 +64,8 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   bf16x8 h, l;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    h[j] = (__bf16)v[j];
-    l[j] = (__bf16)(v[j] - (float)h[j]);
+    h[j] = (vca_e16)v[j];
+    l[j] = (vca_e16)(v[j] - (float)h[j]);
   }
   hi = *reinterpret_cast<uint4*>(&h);
   lo = *reinterpret_cast<uint4*>(&l);
@@ -292,10 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_halo_kernel(HArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if (NSPLIT == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = VCA_MFMA_16x16x32(bh[j], al, acc[i][j]);
+            acc[i][j] = VCA_MFMA_16x16x32(bl[j], ah, acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = VCA_MFMA_16x16x32(bh[j], ah, acc[i][j]);
         }
       }
       wait_b();
@@ -697,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
           if (tap < a.ntaps) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-              acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ts & 1][kk], bh[kk], acc[ts], 0, 0, 0);
+              acc[ts] = VCA_MFMA_32x32x16(af[ts & 1][kk], bh[kk], acc[ts]);
           }
         }
       } else {
@@ -713,9 +712,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
             const int o1 = p1 * 64 + ((colchunk ^ ((p1 >> 2) & 3)) << 4) + colbyte;
             const bf16x8 ah = tr_read8(halo_hi + o0, halo_hi + o1);
             const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
-            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kk], acc[ts], 0, 0, 0);
-            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kk], acc[ts], 0, 0, 0);
-            acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kk], acc[ts], 0, 0, 0);
+            acc[ts] = VCA_MFMA_32x32x16(al, bh[kk], acc[ts]);
+            acc[ts] = VCA_MFMA_32x32x16(ah, bl[kk], acc[ts]);
+            acc[ts] = VCA_MFMA_32x32x16(ah, bh[kk], acc[ts]);
           }
         }
       }
@@ -744,10 +743,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_kernel(WArgs a) {
           if (NSPLIT == 3) {
             const bf16x8 bl = tr_read8(gy_lo + g0, gy_lo + g1);
             const bf16x8 al = tr_read8(halo_lo + o0, halo_lo + o1);
-            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sl], 0, 0, 0);
-            acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sl], 0, 0, 0);
+            acc[sl] = VCA_MFMA_32x32x16(al, bh, acc[sl]);
+            acc[sl] = VCA_MFMA_32x32x16(ah, bl, acc[sl]);
           }
-          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sl], 0, 0, 0);
+          acc[sl] = VCA_MFMA_32x32x16(ah, bh, acc[sl]);
         }
       }
     }
@@ -1033,10 +1032,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_quad_kernel(WArgs a) {
 #pragma unroll
               for (int ch = 0; ch < 2; ++ch) {
                 if (NSPLIT == 3) {
-                  acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[st][ch], acc16[t][ih][ch], 0, 0, 0);
-                  acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[st][ch], acc16[t][ih][ch], 0, 0, 0);
+                  acc16[t][ih][ch] = VCA_MFMA_16x16x32(al, bh[st][ch], acc16[t][ih][ch]);
+                  acc16[t][ih][ch] = VCA_MFMA_16x16x32(ah, bl[st][ch], acc16[t][ih][ch]);
                 }
-                acc16[t][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[st][ch], acc16[t][ih][ch], 0, 0, 0);
+                acc16[t][ih][ch] = VCA_MFMA_16x16x32(ah, bh[st][ch], acc16[t][ih][ch]);
               }
             }
           }
@@ -1273,7 +1272,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_quad8_kernel(WArgs a) 
               const bf16x8 ah = tr_read8(my_hh + o0, my_hh + o1);
 #pragma unroll
               for (int ch = 0; ch < 2; ++ch)
-                acc16[tt][ih][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[st][ch], acc16[tt][ih][ch], 0, 0, 0);
+                acc16[tt][ih][ch] = VCA_MFMA_16x16x32(ah, bh[st][ch], acc16[tt][ih][ch]);
             }
           }
         }
@@ -1319,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wgrad_quad8_kernel(WArgs a) 
 __device__ __forceinline__ float s2_weight(const float* __restrict__ src, int Cin, int tap, int n, int co);
 
 __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, int N, int K, int npad, int nchunk,
-                                        const float* __restrict__ src, __bf16* __restrict__ dst) {
+                                        const float* __restrict__ src, vca_e16* __restrict__ dst) {
   const size_t total = (size_t)taps * nchunk * npad * 32;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1335,8 +1334,8 @@ __global__ void pack_weight_bf16_kernel(int mode, int Cout, int Cin, int taps, i
     else if (mode == 1) v = src[((size_t)k * Cin + n) * taps + (taps - 1 - tap)];  // N = Cin,  K = Cout
     else v = s2_weight(src, Cin, tap, n, k);
   }
-  const __bf16 h = (__bf16)v;
-  const __bf16 l = (__bf16)(v - (float)h);
+  const vca_e16 h = (vca_e16)v;
+  const vca_e16 l = (vca_e16)(v - (float)h);
   const size_t row = ((size_t)(tap * nchunk + chunk) * npad + n) * 64;
   dst[row + j] = h;
   dst[row + 32 + j] = l;
@@ -1362,7 +1361,7 @@ __device__ __forceinline__ float s2_weight(const float* __restrict__ src, int Ci
 // 32 k x 8 n x taps source values of one (channel slice, 8 output rows) group in LDS (the source is contiguous
 // over (k, tap) for a fixed n in mode 0 and over (n, tap) for a fixed k in mode 1) and writes whole 128-byte rows.
 __device__ __forceinline__ void pack_tile_bf16(int mode, int Cin, int taps, int N, int K, int npad, int nchunk,
-                                               const float* __restrict__ src, __bf16* __restrict__ dst, int chunk,
+                                               const float* __restrict__ src, vca_e16* __restrict__ dst, int chunk,
                                                int n0, float* tl /* [8 n][32 k][taps] */) {
   const int k0 = chunk * 32;
   const int tid = threadIdx.x;
@@ -1431,7 +1430,7 @@ __device__ __forceinline__ void pack_tile_bf16(int mode, int Cin, int taps, int 
 __global__ __launch_bounds__(256) void pack_weight_bf16_tiled_kernel(int mode, int Cin, int taps, int N, int K,
                                                                      int npad, int nchunk,
                                                                      const float* __restrict__ src,
-                                                                     __bf16* __restrict__ dst) {
+                                                                     vca_e16* __restrict__ dst) {
   extern __shared__ float tl[];   // [8 n][32 k][taps]
   pack_tile_bf16(mode, Cin, taps, N, K, npad, nchunk, src, dst, blockIdx.x, blockIdx.y * 8, tl);
 }
@@ -1454,7 +1453,7 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_batch_kernel(const vca_p
   const int K = d.mode == 0 ? d.Cin : d.Cout, N = d.mode == 0 ? d.Cout : (d.mode == 1 ? d.Cin : 4 * d.Cin);
   const int npad = (N + 31) / 32 * 32, nchunk = (K + 31) / 32;
   if (local >= nchunk * (npad / 8)) return;
-  pack_tile_bf16(d.mode, d.Cin, d.taps, N, K, npad, nchunk, d.src, reinterpret_cast<__bf16*>(d.dst), local % nchunk,
+  pack_tile_bf16(d.mode, d.Cin, d.taps, N, K, npad, nchunk, d.src, reinterpret_cast<vca_e16*>(d.dst), local % nchunk,
                  (local / nchunk) * 8, tl);
 }
 
@@ -1700,12 +1699,12 @@ extern "C" int vca_pack_weight_bf16(int mode, int Cout, int Cin, int taps, const
   if (taps <= 32) {
     const dim3 grid(nchunk, npad / 8);
     hipLaunchKernelGGL(pack_weight_bf16_tiled_kernel, grid, dim3(256), (size_t)8 * 32 * taps * sizeof(float),
-                       (hipStream_t)stream, mode, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));
+                       (hipStream_t)stream, mode, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<vca_e16*>(dst));
     return vca_launch_status();
   }
   const size_t total = (size_t)taps * nchunk * npad * 32;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     mode, Cout, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<__bf16*>(dst));
+                     mode, Cout, Cin, taps, N, K, npad, nchunk, src, reinterpret_cast<vca_e16*>(dst));
   return vca_launch_status();
 }
 

@@ -557,6 +557,8 @@ bool desc_ok(const vca_conv_desc* d) {
 
 extern "C" int vca_abi_version(void) { return 3; }
 
+extern "C" int vca_elem_type(void) { return VCA_ELEM_TYPE; }
+
 extern "C" int vca_conv_fwd_f32(const vca_conv_desc* d, const float* x, const float* wpack, const float* bias,
                                 const float* in_scale, const float* in_shift, const float* in_alpha,
                                 const float* res, float* y, float* stats, void* stream) {

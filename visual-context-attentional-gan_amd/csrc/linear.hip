@@ -22,7 +22,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct LinArgs {
   vca_lin_desc d;
@@ -43,9 +42,9 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, Frag8& 
   const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
+    const vca_e16 h = (vca_e16)v[e];
     hi.v[e] = h;
-    lo.v[e] = (__bf16)(v[e] - (float)h);
+    lo.v[e] = (vca_e16)(v[e] - (float)h);
   }
 }
 
@@ -131,10 +130,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (NSPLIT == 3) {
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j].v, ah[i].v, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j].v, al[i].v, acc[j][i], 0, 0, 0);
+            acc[j][i] = VCA_MFMA_16x16x32(wl[j].v, ah[i].v, acc[j][i]);
+            acc[j][i] = VCA_MFMA_16x16x32(wh[j].v, al[i].v, acc[j][i]);
           }
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j].v, ah[i].v, acc[j][i], 0, 0, 0);
+          acc[j][i] = VCA_MFMA_16x16x32(wh[j].v, ah[i].v, acc[j][i]);
         }
       }
   }
@@ -270,11 +269,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
-      union { __bf16 e[4]; uint2 u; } h, l;
+      union { vca_e16 e[4]; uint2 u; } h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        h.e[e] = (__bf16)v[e];
-        l.e[e] = (__bf16)(v[e] - (float)h.e[e]);
+        h.e[e] = (vca_e16)v[e];
+        l.e[e] = (vca_e16)(v[e] - (float)h.e[e]);
       }
       *reinterpret_cast<uint2*>(base + adst[j]) = h.u;
       if (NSPLIT == 3) *reinterpret_cast<uint2*>(base + AIMG + adst[j]) = l.u;
@@ -361,10 +360,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (NSPLIT == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = VCA_MFMA_16x16x32(wl[j], ah, acc[i][j]);
+          acc[i][j] = VCA_MFMA_16x16x32(wh[j], al, acc[i][j]);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = VCA_MFMA_16x16x32(wh[j], ah, acc[i][j]);
       }
     }
     // chunk c + 1's weights must have landed; the DMA pieces of the chunks issued behind them (c + 2 .. c + 1 + NR,

@@ -106,6 +106,87 @@ __global__ __launch_bounds__(THR) void adam_kernel(size_t n, float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dynamic loss scaling (half-precision gradients: the backward pass is seeded with `scale` instead of 1, every
+// gradient in the flat buffers is `scale` times too large, and an overflow anywhere shows up as Inf / NaN there).
+// state: int[4] = good steps in a row, overflow flag of the discriminator side, of the generator side, skipped steps.
+// scale: float[2] = scale, 1 / scale.  Everything lives in device words so that a captured step keeps adapting.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THR) void nonfinite_kernel(size_t n4, const float4* __restrict__ g, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < n4; i += (size_t)gridDim.x * THR) {
+    const float4 v = g[i];
+    // (x - x) is 0 for finite x and NaN for Inf / NaN
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad |= !(t == 0.f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void loss_scale_count_kernel(int* __restrict__ step_dev, const int* __restrict__ flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && flag[0] == 0) step_dev[0] += 1;
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ scale, int* __restrict__ state, float growth,
+                                         float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = scale[0];
+  if (state[1] | state[2]) {
+    s = fmaxf(s * backoff, 1.f);
+    state[0] = 0;
+    state[3] += 1;
+  } else if (++state[0] >= interval) {
+    s = fminf(s * growth, 16777216.f);
+    state[0] = 0;
+  }
+  state[1] = 0;
+  state[2] = 0;
+  scale[0] = s;
+  scale[1] = 1.f / s;
+}
+
+// adam_kernel on gradients that carry the loss scale: g / scale enters the update, and the whole launch is a no-op
+// when the side's overflow flag is up (parameters, moments and step count stay as they are).
+__global__ __launch_bounds__(THR) void adam_scaled_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          float* __restrict__ vmax, float b1, float b2, float eps,
+                                                          float wd, const int* __restrict__ step_dev,
+                                                          const float* __restrict__ lr_dev,
+                                                          const float* __restrict__ scale,
+                                                          const int* __restrict__ flag) {
+  if (flag[0]) return;
+  const size_t n4 = n >> 2;
+  const double t = (double)step_dev[0];
+  const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step = lr_dev[0] / bc1, inv = scale[1];
+  for (size_t i = (size_t)blockIdx.x * THR + threadIdx.x; i < n4; i += (size_t)gridDim.x * THR) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    float4 X = vmax ? reinterpret_cast<float4*>(vmax)[i] : make_float4(0, 0, 0, 0);
+    float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w},
+          vv[4] = {V.x, V.y, V.z, V.w}, xx[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * inv + wd * pp[j];
+      mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+      float den;
+      if (vmax) {
+        xx[j] = fmaxf(xx[j], vv[j]);
+        den = sqrtf(xx[j]) / bc2_sqrt + eps;
+      } else {
+        den = sqrtf(vv[j]) / bc2_sqrt + eps;
+      }
+      pp[j] -= step * mm[j] / den;
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (vmax) reinterpret_cast<float4*>(vmax)[i] = make_float4(xx[0], xx[1], xx[2], xx[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // All loss heads of a phase in one launch (train.py:200-231: 18 softplus means, 4 L1 means, 3 R1 squared norms, the
 // sync-loss means and the weighted sums that combine them).  A head e reduces v_e = scale_e * sum_i f_e(x_i[, y_i])
 // and adds w_ek * v_e into up to three slots of the output vector (a reported term and the totals it is part of).
@@ -218,6 +299,36 @@ extern "C" int vca_adam_f32(long long n, float* p, const float* g, float* m, flo
   const float bc1 = (float)bc1d;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n / 4)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, p, g, m,
                      v, vmax, lr, beta1, beta2, eps, weight_decay, bc1, (float)sqrt(bc2d), step_dev, lr_dev);
+  return vca_launch_status();
+}
+
+extern "C" int vca_nonfinite_f32(long long n, const float* g, int* flag, void* stream) {
+  VCA_CHECK_ARG(n > 0 && (n % 4) == 0 && g && flag && (reinterpret_cast<uintptr_t>(g) & 15) == 0);
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for((size_t)n / 4)), dim3(THR), 0, (hipStream_t)stream, (size_t)n / 4,
+                     reinterpret_cast<const float4*>(g), flag);
+  return vca_launch_status();
+}
+
+extern "C" int vca_loss_scale_count(int* step_dev, const int* flag, void* stream) {
+  VCA_CHECK_ARG(step_dev && flag);
+  hipLaunchKernelGGL(loss_scale_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, flag);
+  return vca_launch_status();
+}
+
+extern "C" int vca_loss_scale_update(float* scale, int* state, float growth, float backoff, int interval,
+                                     void* stream) {
+  VCA_CHECK_ARG(scale && state && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1);
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, state, growth,
+                     backoff, interval);
+  return vca_launch_status();
+}
+
+extern "C" int vca_adam_scaled_f32(long long n, float* p, const float* g, float* m, float* v, float* vmax, float beta1,
+                                   float beta2, float eps, float weight_decay, const int* step_dev,
+                                   const float* lr_dev, const float* scale, const int* flag, void* stream) {
+  VCA_CHECK_ARG(n > 0 && (n % 4) == 0 && p && g && m && v && step_dev && lr_dev && scale && flag);
+  hipLaunchKernelGGL(adam_scaled_kernel, dim3(grid_for((size_t)n / 4)), dim3(THR), 0, (hipStream_t)stream, (size_t)n, p,
+                     g, m, v, vmax, beta1, beta2, eps, weight_decay, step_dev, lr_dev, scale, flag);
   return vca_launch_status();
 }
 

@@ -164,7 +164,6 @@ extern "C" int vca_gru_cell_bwd_f32(int B, int H, const float* dout, int dout_st
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct SkinnyArgs {
   const float* x[2];
@@ -237,14 +236,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
       bf16x8 ah, al;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        ah[e] = (__bf16)v[e];
-        al[e] = (__bf16)(v[e] - (float)ah[e]);
+        ah[e] = (vca_e16)v[e];
+        al[e] = (vca_e16)(v[e] - (float)ah[e]);
       }
       if (a.nsplit == 3) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc, 0, 0, 0);
+        acc = VCA_MFMA_32x32x16(al, bh[j], acc);
+        acc = VCA_MFMA_32x32x16(ah, bl[j], acc);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc, 0, 0, 0);
+      acc = VCA_MFMA_32x32x16(ah, bh[j], acc);
     }
   }
   if (lr < NCOL) {
@@ -341,14 +340,14 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_step_kernel(GruFwdArgs a) {
         bf16x8 ah, al;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          ah[e] = (__bf16)v[e];
-          al[e] = (__bf16)(v[e] - (float)ah[e]);
+          ah[e] = (vca_e16)v[e];
+          al[e] = (vca_e16)(v[e] - (float)ah[e]);
         }
         if (a.nsplit == 3) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc, 0, 0, 0);
+          acc = VCA_MFMA_32x32x16(al, bh[j], acc);
+          acc = VCA_MFMA_32x32x16(ah, bl[j], acc);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc, 0, 0, 0);
+        acc = VCA_MFMA_32x32x16(ah, bh[j], acc);
       }
     }
   }

@@ -23,7 +23,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CO = 64, KT = 5, KH = 7, KW = 7;
 constexpr int NQ = KT * KH;          // 35 (kt,kh) rows of 8 kw slots
@@ -40,20 +39,20 @@ constexpr int WFRAG_U4 = 2 * NSTEP * 2 * 64;   // uint4 entries of the packed we
 
 // dst[channel half][step][hi|lo][lane] = the 8 bf16 a lane feeds as the row operand of that step's MFMA:
 // lane (r = lane & 31, h = lane >> 5) holds channel 32*half + r, reduction row q = 2*step + h, slots kw' = 0..7
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ dst) {
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, vca_e16* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * NSTEP * 64) return;
   const int lane = i & 63, s = (i >> 6) % NSTEP, half = i / (64 * NSTEP);
   const int co = half * 32 + (lane & 31), q = 2 * s + (lane >> 5);
-  __bf16* hi = dst + ((size_t)((half * NSTEP + s) * 2 + 0) * 64 + lane) * 8;
-  __bf16* lo = dst + ((size_t)((half * NSTEP + s) * 2 + 1) * 64 + lane) * 8;
+  vca_e16* hi = dst + ((size_t)((half * NSTEP + s) * 2 + 0) * 64 + lane) * 8;
+  vca_e16* lo = dst + ((size_t)((half * NSTEP + s) * 2 + 1) * 64 + lane) * 8;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float v = 0.f;
     if (q < NQ && j >= 1) v = w[(co * NQ + q) * KW + (j - 1)];
-    const __bf16 hv = (__bf16)v;
+    const vca_e16 hv = (vca_e16)v;
     hi[j] = hv;
-    lo[j] = (__bf16)(v - (float)hv);
+    lo[j] = (vca_e16)(v - (float)hv);
   }
 }
 
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_fwd_kernel(int B, int T, int H, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NIMG = NSPLIT == 3 ? 4 : 2;       // [hi copy 0 | hi copy 1 | lo copy 0 | lo copy 1]
   constexpr int SLOT = NIMG * IMG;                // elements per ring slot
-  __bf16* ring = reinterpret_cast<__bf16*>(smem);
+  vca_e16* ring = reinterpret_cast<vca_e16*>(smem);
   const unsigned ring_addr = (unsigned)(uintptr_t)smem;      // LDS byte address (the low half of the flat address)
 
   // Work unit of this workgroup.  Consecutive workgroups are dealt round-robin over the 8 XCDs, so units that share
@@ -172,16 +171,16 @@ __global__ __launch_bounds__(NTHR, 2) void stem_fwd_kernel(int B, int T, int H, 
     }
   };
   auto stage = [&](int f) {       // split the registers into hi/lo and write both copies of frame f's ring slot
-    __bf16* base = ring + ((f + 2 * NRING) % NRING) * SLOT;
+    vca_e16* base = ring + ((f + 2 * NRING) % NRING) * SLOT;
 #pragma unroll
     for (int j = 0; j < NL; ++j)
       if (lds_o[j] >= 0) {
         const int o = lds_o[j];     // multiple of 4 elements: one 8-byte store into copy 0, two 4-byte stores into copy 1
-        union { __bf16 e[4]; uint2 u; unsigned int w[2]; } h, l;
+        union { vca_e16 e[4]; uint2 u; unsigned int w[2]; } h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          h.e[e] = (__bf16)hv[j][e];
-          l.e[e] = (__bf16)(hv[j][e] - (float)h.e[e]);
+          h.e[e] = (vca_e16)hv[j][e];
+          l.e[e] = (vca_e16)(hv[j][e] - (float)h.e[e]);
         }
         *reinterpret_cast<uint2*>(base + o) = h.u;
         *reinterpret_cast<unsigned int*>(base + IMG + o + 2) = h.w[0];
@@ -244,10 +243,10 @@ __global__ __launch_bounds__(NTHR, 2) void stem_fwd_kernel(int B, int T, int H, 
         // pixels are the row operand: D[row = pixel][col = channel], so a lane owns one channel, a register quad four
         // pixels, and every store instruction writes whole 128-byte lines (32 channels of a pixel)
         if (NSPLIT == 3) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s % NB].v, wl[s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s % NB].v, wh[s], acc, 0, 0, 0);
+          acc = VCA_MFMA_32x32x16(fh[s % NB].v, wl[s], acc);
+          acc = VCA_MFMA_32x32x16(fl[s % NB].v, wh[s], acc);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s % NB].v, wh[s], acc, 0, 0, 0);
+        acc = VCA_MFMA_32x32x16(fh[s % NB].v, wh[s], acc);
       }
       // D[row][col]: col = lane & 31 (channel within the half), row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5) = pixel
       // of the tile (column row & 15 of patch row prow0 + 2 * tile + (row >> 4))
@@ -287,7 +286,7 @@ extern "C" long long vca_stem_pack_bytes() { return (long long)WFRAG_U4 * 16; }
 extern "C" int vca_stem_pack_weight(const float* w, void* wpack, void* stream) {
   VCA_CHECK_ARG(w && wpack);
   hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((2 * NSTEP * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<__bf16*>(wpack));
+                     reinterpret_cast<vca_e16*>(wpack));
   return vca_launch_status();
 }
 

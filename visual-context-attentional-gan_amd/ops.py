@@ -118,17 +118,35 @@ def _wdims(w):
 _precision = ['fp32']
 
 
+_FP16_MODES = {'fp16x3': 'bf16x3', 'fp16': 'bf16', 'fp16-mixed': 'mixed'}
+
+
 def set_precision(mode):
     """Arithmetic of the matrix-core convolutions: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, three bf16 MFMAs
     per product, fp32 accumulate: ~fp32 accuracy), 'bf16' (single bf16 product) or 'mixed' (bf16x3 in every forward
     product and in the gradient chain that yields the R1 penalty, so outputs and loss values keep fp32-level parity,
-    and single bf16 products in the input/weight gradients, as bf16 mixed-precision training does)."""
-    assert mode in ('fp32', 'bf16x3', 'bf16', 'mixed')
-    _precision[0] = mode
+    and single bf16 products in the input/weight gradients, as bf16 mixed-precision training does).
+    'fp16x3' / 'fp16' / 'fp16-mixed' are the same three schemes on IEEE half operands (the library's second build):
+    11 significant bits per product instead of 8, but a normal range that ends at 6e-5, so a training step in these
+    modes seeds its backward passes with a loss scale (LossScaler)."""
+    assert mode in ('fp32', 'bf16x3', 'bf16', 'mixed') or mode in _FP16_MODES, mode
+    elem = 'fp16' if mode in _FP16_MODES else 'bf16'
+    if mode != 'fp32' and elem != _lib.ELEM[0]:
+        _lib.ELEM[0] = elem
+        _param_epoch[0] += 1          # packed weights are element-type specific: every cached copy is stale
+    _precision[0] = _FP16_MODES.get(mode, mode)
 
 
 def get_precision():
+    """The mode set_precision() was given."""
+    if _lib.ELEM[0] == 'fp16' and _precision[0] != 'fp32':
+        return {v: k for k, v in _FP16_MODES.items()}[_precision[0]]
     return _precision[0]
+
+
+def half_gradients():
+    """True when gradients go through IEEE-half products (and therefore need a loss scale)."""
+    return _lib.ELEM[0] == 'fp16' and _precision[0] != 'fp32'
 
 
 def _pack(w, mode):
@@ -242,11 +260,11 @@ class use_precision:
         self.mode = mode
 
     def __enter__(self):
-        self.prev = _precision[0]
+        self.prev = get_precision()
         set_precision(self.mode)
 
     def __exit__(self, *exc):
-        _precision[0] = self.prev
+        set_precision(self.prev)
 
 
 def _nsplit(backward=False):
@@ -2061,6 +2079,38 @@ def flatten_modules(modules):
     return out, allp, allg
 
 
+class LossScaler:
+    """Dynamic loss scale for half-precision gradients, all of it in device words (a captured step keeps adapting):
+    seed the backward passes with seed(), hand the scaler to FusedAdam.step(), call update() once per training step
+    after both optimizers.  Semantics of torch.cuda.amp.GradScaler: an overflow (Inf / NaN in a side's gradients)
+    skips that side's optimizer step and multiplies the scale by `backoff`; `interval` clean steps in a row multiply it
+    by `growth`."""
+
+    def __init__(self, device, init_scale=65536.0, growth=2.0, backoff=0.5, interval=2000):
+        self.scale = torch.tensor([init_scale, 1.0 / init_scale], device=device, dtype=torch.float32)
+        self.state = torch.zeros(4, device=device, dtype=torch.int32)   # clean steps, flag D, flag G, skipped steps
+        self.growth, self.backoff, self.interval = float(growth), float(backoff), int(interval)
+
+    def seed(self, onehot):
+        """The backward seed: `onehot` times the current scale (a device-side product: follows the scale in replay)."""
+        return onehot * self.scale[0]
+
+    def update(self):
+        check(_lib.lib().vca_loss_scale_update(self.scale.data_ptr(), self.state.data_ptr(), self.growth, self.backoff,
+                                               self.interval, stream()), 'loss_scale_update')
+
+    def set_scale(self, value):
+        self.scale.copy_(torch.tensor([value, 1.0 / value], dtype=torch.float32))
+
+    @property
+    def value(self):
+        return float(self.scale[0])
+
+    @property
+    def skipped(self):
+        return int(self.state[3])
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (coupled L2 weight decay, optional amsgrad; train.py:82-83) as one kernel launch
     per flat buffer.  `groups` is a list of (flat_params, flat_grads) from flatten_module.
@@ -2096,16 +2146,33 @@ class FusedAdam:
             self.lr_dev.copy_(torch.full((1,), lr, dtype=torch.float32), non_blocking=False)
             self._lr_written = lr
 
-    def step(self):
-        self.t += 1
-        self.t_dev += 1
+    def step(self, scaler=None, side=0):
+        """scaler: a LossScaler whose scale the gradients carry; side: 0 / 1, which of its overflow flags this
+        optimizer raises (discriminator / generator side).  With a scaler the step is skipped on the device when any
+        gradient is Inf / NaN (parameters, moments and the step count stay)."""
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
+        L = _lib.lib()
+        if scaler is not None:
+            flag = scaler.state.data_ptr() + 4 * (1 + side)
+            for _, g in self.groups:
+                check(L.vca_nonfinite_f32(g.numel(), ptr(g), flag, stream()), 'nonfinite')
+            check(L.vca_loss_scale_count(self.t_dev.data_ptr(), flag, stream()), 'loss_scale_count')
+            self.t += 1                # host copy: an upper bound once a step has been skipped
+        else:
+            self.t += 1
+            self.t_dev += 1
         lr = self.param_groups[0]['lr']
         for (f, g), st in zip(self.groups, self.state):
-            check(_lib.lib().vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
-                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
-                                          self.t_dev.data_ptr(), self.lr_dev.data_ptr(), stream()), 'adam')
+            if scaler is not None:
+                check(L.vca_adam_scaled_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']),
+                                            self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                            self.t_dev.data_ptr(), self.lr_dev.data_ptr(), scaler.scale.data_ptr(),
+                                            flag, stream()), 'adam_scaled')
+            else:
+                check(L.vca_adam_f32(f.numel(), ptr(f), ptr(g), ptr(st['m']), ptr(st['v']), ptr(st['vmax']), lr,
+                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                     self.t_dev.data_ptr(), self.lr_dev.data_ptr(), stream()), 'adam')
             ep = _flat_epoch.get(f.data_ptr())
             if ep is not None:
                 ep[0] += 1

@@ -111,8 +111,13 @@ class _Heads:
 class GanStep:
     """Callable running one full G+D step; variant 'grid' = train.py, 'lrs' = train_LRS.py."""
 
-    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False, ctc=None, overlap=None):
-        """overlap: run the gradient exchanges beside the parts of the step that do not need their results (only
+    def __init__(self, models, optimizers, variant='grid', group=None, force_exchange=False, ctc=None, overlap=None,
+                 scaler=None):
+        """scaler: an ops.LossScaler; required (and created by default) when the precision mode computes gradients in
+        IEEE half ('fp16', 'fp16-mixed', 'fp16x3'; BASELINE configs[4] "fp16 with loss-scaling"): both backward passes
+        are seeded with the scale, the optimizers divide it out and skip their step on overflow, the scale adapts at
+        the end of every step.  The reported losses are unscaled.
+        overlap: run the gradient exchanges beside the parts of the step that do not need their results (only
         with an active exchange; default: off, VCA_EXCHANGE_OVERLAP=1 turns it on); see schedule().
         ctc: None, or dict(front=Audio_front, back=Backend, weight=w): the multi-task configuration (BASELINE
         configs[4]) adds w * CTC(ASR scorer(g3), text) to gen_loss.  The reference ships that scorer for inference only
@@ -135,6 +140,9 @@ class GanStep:
             overlap = os.environ.get('VCA_EXCHANGE_OVERLAP', '0') == '1'
         self.overlap = bool(overlap) and self.g_exchange.active
         self._seeds = {}
+        if scaler is None and ops.half_gradients():
+            scaler = ops.LossScaler(next(models['gen'].parameters()).device)
+        self.scaler = scaler
         if dist.is_available() and dist.is_initialized():
             ops.set_seed(torch.initial_seed(), dist.get_rank(group))   # each replica draws its own dropout masks
 
@@ -310,7 +318,7 @@ class GanStep:
             t = torch.zeros(n, device=device, dtype=torch.float32)
             t[i] = 1.0
             self._seeds[key] = t
-        return t
+        return t if self.scaler is None else self.scaler.seed(t)
 
     def g_phase(self):
         """d_optimizer.step(), then the generator losses and their backward (train.py:211-235)."""
@@ -327,7 +335,7 @@ class GanStep:
         """d_optimizer.step(), the generator losses and their backward pass; with overlap the pass ends at the phoneme
         features and g_trunk() takes it through the visual front-end."""
         m, st = self.m, self._st
-        self.d_opt.step()
+        self.d_opt.step(self.scaler, 0)
         g1, g2, g3 = st['g']
         phon, sd, T = st['phon'], st['sd'], st['T']
         dis = (m['dis1'], m['dis2'], m['dis3'])
@@ -399,7 +407,9 @@ class GanStep:
 
     def finish(self):
         """g_optimizer.step() (train.py:236); returns the step's losses and outputs."""
-        self.g_opt.step()
+        self.g_opt.step(self.scaler, 1)
+        if self.scaler is not None:
+            self.scaler.update()
         ops.step_end(self._st['g3'].device)
         out, self._st = self._st, None
         return out
