@@ -454,9 +454,23 @@ def main():
                 g2(data['mel'], data['spec'], data['vid'])
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t1) / args.steps * 1e3
-            ops.set_precision(args.precision)
             res['alt_precision'] = {'dtype': alt, 'dtype_note': DTYPE_NOTE[alt], 'ms_per_step': round(ms2, 2),
                                     'value': round(frames / (ms2 * 1e-3), 1)}
+            # and on IEEE-half operands under a dynamic loss scale (the library's second build)
+            ops.set_precision('fp16-mixed')
+            step.scaler = ops.LossScaler(device)
+            g3 = train_step.GraphedStep(step, data['mel'], data['spec'], data['vid'], data['vid_len'], 'device')
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g3(data['mel'], data['spec'], data['vid'])
+            torch.cuda.synchronize()
+            ms3 = (time.perf_counter() - t1) / args.steps * 1e3
+            res['alt_precision_half'] = {'dtype': 'fp16-mixed', 'dtype_note': DTYPE_NOTE['fp16-mixed'],
+                                         'ms_per_step': round(ms3, 2), 'value': round(frames / (ms3 * 1e-3), 1),
+                                         'loss_scale': step.scaler.value, 'skipped_steps': step.scaler.skipped}
+            step.scaler = None
+            ops.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline and not lrs:
             res['cpu_baseline'] = cpu_baseline()
         sys.stdout.flush()
