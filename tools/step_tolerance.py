@@ -30,13 +30,21 @@ for prec in (sys.argv[1:] or ['fp32', 'bf16x3', 'mixed', 'mixed+r1x3']):
             b = fixtures.make_batch(B, T, H, int(g['seed']) + s, list(g['lens']))
             b = {k: (v.cuda() if k != 'vid_len' else v) for k, v in b.items()}
             # the step phase by phase, so that the gradients d_optimizer.step() consumes can be read in between
+            sc = step.scaler.value if step.scaler is not None else 1.0   # half modes: gradients carry the loss scale
+            opts = (step.g_opt, step.d_opt)
             step.d_phase(b['mel'], b['spec'], b['vid'], b['vid_len'], b['noise'])
             torch.cuda.synchronize()
-            dm = measure_d_side(m, step._st['phon_d'].grad, g, s)
+            for o in opts:
+                o.all_grads.mul_(1.0 / sc)
+            dm = measure_d_side(m, step._st['phon_d'].grad / sc, g, s)
+            for o in opts:
+                o.all_grads.mul_(sc)
             step.d_exchange.reduce()
             step.g_phase()
             step.g_exchange.reduce()
             res = step.finish()
+            for o in opts:
+                o.all_grads.mul_(1.0 / sc)
             res = {k: (v.item() if v.numel() == 1 else v.cpu()) for k, v in res.items()}
             # D: after the step the reference's discriminators hold the gradient of gen_loss, which nothing consumes
             mt = measure_step(m, res, g, s, D)
